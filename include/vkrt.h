@@ -1,0 +1,207 @@
+/*
+ * vkrt.h -- C ABI of the MI355X-native ray-tracing path.
+ *
+ * This is the drop-in boundary for the path-tracing path of vk-raytracing-engine.
+ * The reference has no plugin ABI; its ray-tracing path is entered through member
+ * functions of `HelloVulkan` plus the data contract of shaders/host_device.h.  Each
+ * entry point below names the reference interface it replaces (file:line relative to
+ * the reference tree).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ *   reference call (main.cpp)                      this ABI
+ *   ---------------------------------------------  -------------------------------
+ *   loadGltfScene()        hello_vulkan.cpp:327     vkrt_scene_create (flat arrays)
+ *   createBottomLevelASGltf()  :1001                vkrt_accel_build
+ *   createTopLevelAsGltf()     :1031                vkrt_accel_build (same call)
+ *   updateUniformBuffer()      :61                  GlobalUniforms* argument
+ *   pathtrace()                :1423                vkrt_pathtrace
+ *   resetFrame()/updateFrame() :1501-1521           caller-owned PushConstantRay.frame
+ *   destroyResources()         :518                 vkrt_scene_destroy
+ *
+ * Ownership: every input array is copied at vkrt_scene_create (the caller may free
+ * it on return, like the reference's staging upload, hello_vulkan.cpp:353-357).  The
+ * radiance image is caller-owned device memory (rgba32f, tightly packed rows); it is
+ * read-modify-written when PushConstantRay.frame > 0 (raytrace.rgen:136-141).
+ * Errors: int return codes, 0 = VKRT_OK; text via vkrt_last_error(); nothing throws
+ * across the ABI.  Threading: one host thread per scene handle at a time; work is
+ * enqueued on the caller's HIP stream (hipStream_t passed as void*; NULL = default).
+ * The library never falls back to a CPU path: without a HIP device every compute
+ * entry point returns VKRT_ERR_NO_DEVICE.
+ */
+#ifndef VKRT_H
+#define VKRT_H
+
+#include <stdint.h>
+#include "vkrt_host_device.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKRT_ABI_VERSION 1
+
+enum vkrt_status {
+  VKRT_OK = 0,
+  VKRT_ERR_INVALID_ARGUMENT = 1,
+  VKRT_ERR_NO_DEVICE = 2,
+  VKRT_ERR_HIP = 3,
+  VKRT_ERR_OUT_OF_MEMORY = 4,
+  VKRT_ERR_NOT_BUILT = 5,     /* vkrt_pathtrace before vkrt_accel_build */
+  VKRT_ERR_UNSUPPORTED = 6
+};
+
+typedef struct vkrt_scene vkrt_scene; /* opaque; one per GPU */
+
+/* One glTF primitive-mesh, as nvh::GltfPrimMesh is consumed by the reference
+ * (hello_vulkan.cpp:363-368 for the shader lookup, :955-987 for the BLAS ranges:
+ * primitiveCount = indexCount/3, firstVertex = vertexOffset, maxVertex = vertexCount). */
+typedef struct vkrt_prim_mesh {
+  uint32_t firstIndex;    /* into indices[] */
+  uint32_t indexCount;    /* multiple of 3 */
+  uint32_t vertexOffset;  /* added to every index value */
+  uint32_t vertexCount;
+  int32_t  materialIndex; /* may be -1; the shader clamps with max(0, .) (raytrace.rchit:38) */
+} vkrt_prim_mesh;
+
+/* One drawable node = one TLAS instance (hello_vulkan.cpp:1035-1043):
+ * transform = worldMatrix, instanceCustomIndex = primMesh, mask 0xFF, cull disabled. */
+typedef struct vkrt_node {
+  float   worldMatrix[16]; /* column-major object->world */
+  int32_t primMesh;
+} vkrt_node;
+
+/* One sampled image: 8-bit RGBA, row-major, top row first (what tinygltf/stb hand the
+ * reference, hello_vulkan.cpp:482-499).  is_srgb follows getImageFormat
+ * (hello_vulkan.cpp:417-443).  Sampler: bilinear, REPEAT, LOD 0 (:448-454 and SURVEY
+ * Appendix A 27-29).  textures[i] here is glTF texture i (already resolved to its
+ * source image, :505-509). */
+typedef struct vkrt_texture {
+  uint32_t       width;
+  uint32_t       height;
+  const uint8_t* rgba8;
+  int32_t        is_srgb;
+} vkrt_texture;
+
+/* Flat scene arrays exactly as the reference uploads them (hello_vulkan.cpp:353-379):
+ * SoA vertex attributes shared by all primitive-meshes, one u32 index buffer. */
+typedef struct vkrt_scene_desc {
+  uint32_t struct_size;        /* = sizeof(vkrt_scene_desc), ABI check */
+  uint32_t vertex_count;
+  const float*    positions;   /* vec3[vertex_count]  (m_gltfScene.m_positions)  */
+  const float*    normals;     /* vec3[vertex_count]  (m_normals)                */
+  const float*    tangents;    /* vec4[vertex_count]  (m_tangents, w=handedness) */
+  const float*    texcoords0;  /* vec2[vertex_count]  (m_texcoords0)             */
+  const uint32_t* indices;     /* u32[index_count]    (m_indices)                */
+  uint32_t index_count;
+  uint32_t prim_mesh_count;
+  const vkrt_prim_mesh*  prim_meshes;
+  const GltfPBRMaterial* materials;
+  uint32_t material_count;
+  uint32_t light_count;
+  const GltfLight*       lights;
+  const vkrt_node*       nodes;
+  uint32_t node_count;
+  uint32_t texture_count;      /* 0 => a 1x1 white dummy is bound (hello_vulkan.cpp:468-472) */
+  const vkrt_texture*    textures;
+} vkrt_scene_desc;
+
+/* Acceleration-structure build selection (replaces
+ * VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR, hello_vulkan.cpp:1010,1046). */
+enum vkrt_build_flags {
+  VKRT_BUILD_LBVH_GPU = 0x1,  /* Morton-code LBVH built by HIP kernels on the device  */
+  VKRT_BUILD_SAH_HOST = 0x2,  /* binned-SAH BVH built by the C++ host, then uploaded  */
+  VKRT_BUILD_DEFAULT  = 0x2
+};
+
+/* Image-space sharding (replaces the single vkCmdTraceRaysKHR(W,H,1) grid,
+ * hello_vulkan.cpp:1446).  The full launch size stays gl_LaunchSizeEXT for every
+ * shard so seeds and camera rays depend on global pixel coordinates only.
+ * Rows are dealt in strips: strip s = rows [s*strip_rows, (s+1)*strip_rows) belongs to
+ * shard (s % shard_count).  The shard's output buffer holds its strips stacked in
+ * increasing s, full_width pixels per row.  strip_rows = 0 means "the whole image". */
+typedef struct vkrt_shard {
+  uint32_t full_width;
+  uint32_t full_height;
+  uint32_t strip_rows;
+  uint32_t shard_count;
+  uint32_t shard_index;
+} vkrt_shard;
+
+enum vkrt_trace_flags {
+  /* Default reproduces raytrace.rgen:27: seed index = y*x + x.  This flag selects the
+   * collision-free y*full_width + x instead (not parity). */
+  VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1,
+  /* Count BVH nodes visited / triangles tested as well (slower instrumented kernel). */
+  VKRT_TRACE_COUNT_TRAVERSAL = 0x2
+};
+
+typedef struct vkrt_trace_opts {
+  uint32_t seed;   /* replaces int(clockARB()) in raytrace.rgen:27 */
+  uint32_t flags;  /* vkrt_trace_flags */
+} vkrt_trace_opts;
+
+/* Totals accumulated by device atomics since the last vkrt_counters_reset. */
+typedef struct vkrt_counters {
+  uint64_t rays_closest;   /* traceRayEXT calls of raytrace.rgen:64-75          */
+  uint64_t rays_shadow;    /* traceRayEXT calls of raytrace.rgen:85-97          */
+  uint64_t hits;           /* raytrace.rchit invocations                        */
+  uint64_t diffuse_hits;   /* rchit invocations that took the diffuse lobe      */
+  uint64_t tex_taps;       /* texture() calls                                   */
+  uint64_t pixels;         /* rgen invocations                                  */
+  uint64_t nodes_visited;  /* only with VKRT_TRACE_COUNT_TRAVERSAL              */
+  uint64_t tris_tested;    /* only with VKRT_TRACE_COUNT_TRAVERSAL              */
+} vkrt_counters;
+
+typedef struct vkrt_accel_info {
+  uint32_t triangle_count;   /* instanced (flattened) triangles */
+  uint32_t node_count;       /* BVH nodes in the traversal layout */
+  uint32_t max_depth;
+  uint32_t build_flags;      /* which builder produced it */
+  float    sah_cost;         /* SAH cost of the tree, traversal 1 / intersect 1 */
+  float    build_ms;         /* wall time of the last build */
+  uint64_t node_bytes;
+  uint64_t triangle_bytes;
+} vkrt_accel_info;
+
+/* ---- library ---------------------------------------------------------------------- */
+int         vkrt_abi_version(void);
+const char* vkrt_last_error(void);       /* thread-local, never NULL */
+int         vkrt_device_count(void);     /* 0 without a HIP device */
+
+/* ---- scene (replaces loadGltfScene's uploads, hello_vulkan.cpp:353-381) ----------- */
+int  vkrt_scene_create(const vkrt_scene_desc* desc, int device, vkrt_scene** out);
+void vkrt_scene_destroy(vkrt_scene* scene);
+
+/* ---- acceleration structure (replaces createBottomLevelASGltf :1001-1011 and
+ *      createTopLevelAsGltf :1031-1047) ------------------------------------------- */
+int vkrt_accel_build(vkrt_scene* scene, uint32_t build_flags, void* hip_stream);
+int vkrt_accel_get_info(const vkrt_scene* scene, vkrt_accel_info* out);
+
+/* ---- path trace (replaces HelloVulkan::pathtrace :1423-1448 = one
+ *      vkCmdTraceRaysKHR over raytrace.rgen/.rchit/.rmiss/raytraceShadow.rmiss) ---- */
+uint32_t vkrt_shard_rows(const vkrt_shard* shard); /* rows of the shard's buffer */
+int vkrt_pathtrace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam,
+                   const vkrt_trace_opts* opts, const vkrt_shard* shard,
+                   float* rgba32f_device, void* hip_stream);
+
+/* ---- counters / timing ------------------------------------------------------------ */
+int vkrt_counters_reset(vkrt_scene* scene, void* hip_stream);
+int vkrt_counters_read(vkrt_scene* scene, vkrt_counters* out); /* synchronises the device */
+/* Device time of the most recent vkrt_pathtrace kernel on this scene in milliseconds,
+ * from HIP events recorded on the launch stream (synchronises on the stop event). */
+int vkrt_last_trace_ms(vkrt_scene* scene, float* ms);
+
+/* ---- test hooks (used by tests/ to compare single pieces with the oracle) ---------- */
+/* Closest-hit query for n rays: o,d = vec3[n] host arrays; tmin/tmax scalars.
+ * Writes t,u,v (float[n]) and the flattened triangle id gid (int32[n], -1 = miss). */
+int vkrt_debug_trace_rays(vkrt_scene* scene, uint32_t n, const float* origins,
+                          const float* directions, float tmin, float tmax, int any_hit,
+                          float* t, float* u, float* v, int32_t* gid);
+/* Evaluate a device math primitive elementwise (op: 0 sin, 1 cos, 2 sqrt, 3 a/b,
+ * 4 pow5, 5 1/sqrt-normalise x of (a,b,0)); host arrays in/out. */
+int vkrt_debug_eval_math(int device, int op, uint32_t n, const float* a, const float* b,
+                         float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKRT_H */

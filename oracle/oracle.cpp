@@ -1,0 +1,1299 @@
+/*
+ * oracle.cpp -- scalar CPU restatement of the reference's path-tracing path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
+ * only as the checker / reported CPU baseline.  The product (libvkrt.so) never links,
+ * loads or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden images or known-answer vectors
+ * for this path and cannot be built or run here (needs Vulkan,
+ * glslang, nvpro_core, NRD/NRI and an RT GPU).  This restatement follows the GLSL
+ * sources line by line (citations below are relative to the reference tree); it is
+ * pinned only by (i) the integer PRNG known answers in tests/golden/prng_kat.json,
+ * (ii) an independent numpy-float32 restatement of the shading functions
+ * (oracle/np_shading.py), (iii) brute-force vs BVH agreement, (iv) analytic images.
+ *
+ * Arithmetic profile ("vkrt math profile") -- what the GLSL leaves
+ * implementation-defined is fixed as follows, identically in the HIP kernels:
+ *   - IEEE-754 binary32, round-to-nearest-even, subnormals kept, no contraction
+ *     (-ffp-contract=off); + - * / sqrt correctly rounded.
+ *   - shader math is evaluated in source order, left to right, without FMA;
+ *     dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z.
+ *   - normalize(v) = v * (1/sqrt(dot(v,v))); length(v) = sqrt(dot(v,v)).
+ *   - min(x,y) = y<x ? y : x ; max(x,y) = x<y ? y : x (GLSL 4.60 section 8.3).
+ *   - sin/cos: Cody-Waite reduction by pi/4 + degree-7/8 minimax polynomials with
+ *     explicit fmaf (vk_sincos below); pow(x,5) = ((x*x)*(x*x))*x.
+ *   - ray/triangle and ray/box tests (driver-defined in the reference, raytrace.rgen:64)
+ *     use explicit fmaf as written in isect_* below; closest hit = smallest t, ties
+ *     broken by the smallest flattened triangle id (instance-major, then primitive).
+ */
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../include/vkrt.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// vec3 helpers (source-order float arithmetic)
+// ------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 v3(float s) { return V3{s, s, s}; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+inline V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross(V3 a, V3 b)
+{
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline float length(V3 a) { return sqrtf(dot(a, a)); }
+inline V3 normalize(V3 a)
+{
+  float inv = 1.0f / sqrtf(dot(a, a));
+  return a * inv;
+}
+inline float glsl_min(float x, float y) { return (y < x) ? y : x; }
+inline float glsl_max(float x, float y) { return (x < y) ? y : x; }
+inline float glsl_clamp(float x, float lo, float hi) { return glsl_min(glsl_max(x, lo), hi); }
+inline V3 glsl_mix(V3 a, V3 b, float t) { return a * (1.0f - t) + b * t; }
+// reflect(I,N) = I - 2*dot(N,I)*N  (GLSL 4.60 section 8.5)
+inline V3 glsl_reflect(V3 I, V3 N) { return I - (2.0f * dot(N, I)) * N; }
+
+// globals.glsl:4-5
+const float M_PI_F = 3.14159265f;
+const float M_INV_PI_F = 1.0f / M_PI_F;
+
+// ------------------------------------------------------------------------------------------
+// math profile: sin / cos / pow5
+// ------------------------------------------------------------------------------------------
+inline void vk_sincos(float x, float* s_out, float* c_out)
+{
+  const float FOPI = 1.27323954473516f;  // 4/pi
+  const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+  float ax = fabsf(x);
+  int j = (int)(ax * FOPI);
+  j = (j + 1) & ~1;
+  float y = (float)j;
+  float r = fmaf(y, -DP1, ax);
+  r = fmaf(y, -DP2, r);
+  r = fmaf(y, -DP3, r);
+  float z = r * r;
+  float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                  z * z, fmaf(-0.5f, z, 1.0f));
+  int q = (j >> 1) & 3;
+  float s, c;
+  if(q == 0) { s = ps; c = pc; }
+  else if(q == 1) { s = pc; c = -ps; }
+  else if(q == 2) { s = -ps; c = -pc; }
+  else { s = -pc; c = ps; }
+  if(x < 0.0f) s = -s;
+  *s_out = s;
+  *c_out = c;
+}
+inline float vk_sin(float x) { float s, c; vk_sincos(x, &s, &c); return s; }
+inline float vk_cos(float x) { float s, c; vk_sincos(x, &s, &c); return c; }
+inline float vk_pow5(float x) { float x2 = x * x; return (x2 * x2) * x; }
+
+// ------------------------------------------------------------------------------------------
+// random.glsl:6-33  (integer exact)
+// ------------------------------------------------------------------------------------------
+inline uint32_t tea(uint32_t val0, uint32_t val1)
+{
+  uint32_t v0 = val0, v1 = val1, s0 = 0u;
+  for(uint32_t n = 0; n < 16u; n++)
+  {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  return v0;
+}
+inline uint32_t lcg(uint32_t& prev)
+{
+  prev = 1664525u * prev + 1013904223u;
+  return prev & 0x00FFFFFFu;
+}
+inline float rnd(uint32_t& prev) { return (float)lcg(prev) / (float)0x01000000; }
+
+// random.glsl:35-45
+inline V3 samplingHemisphere(uint32_t& seed, V3 x, V3 y, V3 z)
+{
+  float r1 = rnd(seed);
+  float r2 = rnd(seed);
+  float sq = sqrtf(r1);
+  float sn, cs;
+  vk_sincos(2 * M_PI_F * r2, &sn, &cs);
+  V3 direction = v3(cs * sq, sn * sq, sqrtf(1 - r1));
+  direction = direction.x * x + direction.y * y + direction.z * z;
+  return direction;
+}
+// random.glsl:47-54
+inline void createCoordinateSystem(V3 N, V3& Nt, V3& Nb)
+{
+  if(fabsf(N.x) > fabsf(N.y))
+    Nt = v3(N.z, 0, -N.x) / sqrtf(N.x * N.x + N.z * N.z);
+  else
+    Nt = v3(0, -N.z, N.y) / sqrtf(N.y * N.y + N.z * N.z);
+  Nb = cross(N, Nt);
+}
+// random.glsl:56-70
+inline V3 samplingNDF_GGXTR(uint32_t& seed, float alpha2)
+{
+  float r1 = rnd(seed);
+  float r2 = rnd(seed);
+  float cosTheta = sqrtf((1.0f - r2) / ((alpha2 - 1.0f) * r2 + 1.0f));
+  float sinTheta = glsl_clamp(sqrtf(1.0f - cosTheta * cosTheta), 0.0f, 1.0f);
+  float phi = r1 * 2.0f * M_PI_F;
+  float sinPhi, cosPhi;
+  vk_sincos(phi, &sinPhi, &cosPhi);
+  return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+
+// ------------------------------------------------------------------------------------------
+// Scene (flat arrays of include/vkrt.h copied; instances flattened to world space)
+// ------------------------------------------------------------------------------------------
+struct Instance
+{
+  float o2w[3][4];  // row-major 3x4 of the column-major worldMatrix
+  float w2o[3][3];  // inverse of the upper-left 3x3
+  int32_t primMesh;
+};
+struct Tri  // world-space triangle for traversal
+{
+  V3 v0, e1, e2;
+  uint32_t gid, inst, prim;
+};
+struct Tex
+{
+  uint32_t w, h;
+  std::vector<uint8_t> rgba;
+  bool srgb;
+};
+struct Aabb
+{
+  float lo[3], hi[3];
+};
+struct BvhNode  // internal node: two child boxes + refs (canonical 64-byte node of SURVEY 8d)
+{
+  Aabb box[2];
+  int32_t child[2];  // >=0 internal node index, <0 : ~leafIndex
+};
+struct BvhLeaf
+{
+  uint32_t first, count;  // into triOrder
+};
+
+struct Counters
+{
+  uint64_t rays_closest = 0, rays_shadow = 0, hits = 0, diffuse_hits = 0, tex_taps = 0, pixels = 0,
+           nodes_visited = 0, tris_tested = 0;
+  void add(const Counters& o)
+  {
+    rays_closest += o.rays_closest; rays_shadow += o.rays_shadow; hits += o.hits;
+    diffuse_hits += o.diffuse_hits; tex_taps += o.tex_taps; pixels += o.pixels;
+    nodes_visited += o.nodes_visited; tris_tested += o.tris_tested;
+  }
+};
+
+}  // namespace
+
+struct orc_scene
+{
+  std::vector<V3> pos, nrm;
+  std::vector<float> tan4;  // vec4
+  std::vector<float> uv2;   // vec2
+  std::vector<uint32_t> idx;
+  std::vector<vkrt_prim_mesh> pm;
+  std::vector<GltfPBRMaterial> mats;
+  std::vector<GltfLight> lights;
+  std::vector<Instance> inst;
+  std::vector<Tex> tex;
+  float srgb_lut[256];
+  std::vector<Tri> tris;  // flattened, gid order
+  // BVH
+  std::vector<BvhNode> nodes;
+  std::vector<BvhLeaf> leaves;
+  std::vector<uint32_t> triOrder;
+  bool rootIsLeaf = false;
+  uint32_t maxDepth = 0;
+  double sahCost = 0;
+};
+
+namespace {
+
+// Inverse of the upper-left 3x3 in double, cofactor form (fixed operation order; the
+// product's host code computes W2O the same way so both sides hold identical floats).
+void invert3x3(const float m[3][4], float out[3][3])
+{
+  double a = m[0][0], b = m[0][1], c = m[0][2];
+  double d = m[1][0], e = m[1][1], f = m[1][2];
+  double g = m[2][0], h = m[2][1], i = m[2][2];
+  double A = e * i - f * h;
+  double B = -(d * i - f * g);
+  double C = d * h - e * g;
+  double det = a * A + b * B + c * C;
+  double inv = 1.0 / det;
+  out[0][0] = (float)(A * inv);
+  out[0][1] = (float)(-(b * i - c * h) * inv);
+  out[0][2] = (float)((b * f - c * e) * inv);
+  out[1][0] = (float)(B * inv);
+  out[1][1] = (float)((a * i - c * g) * inv);
+  out[1][2] = (float)(-(a * f - c * d) * inv);
+  out[2][0] = (float)(C * inv);
+  out[2][1] = (float)(-(a * h - b * g) * inv);
+  out[2][2] = (float)((a * e - b * d) * inv);
+}
+
+// gl_ObjectToWorldEXT * vec4(p,1): column0*x + column1*y + column2*z + column3*1
+inline V3 xformPoint(const Instance& in, V3 p)
+{
+  V3 r;
+  r.x = ((in.o2w[0][0] * p.x + in.o2w[0][1] * p.y) + in.o2w[0][2] * p.z) + in.o2w[0][3];
+  r.y = ((in.o2w[1][0] * p.x + in.o2w[1][1] * p.y) + in.o2w[1][2] * p.z) + in.o2w[1][3];
+  r.z = ((in.o2w[2][0] * p.x + in.o2w[2][1] * p.y) + in.o2w[2][2] * p.z) + in.o2w[2][3];
+  return r;
+}
+// vec3(n * gl_WorldToObjectEXT): component j = dot(n, column j of W2O)
+inline V3 xformNormal(const Instance& in, V3 n)
+{
+  V3 r;
+  r.x = (n.x * in.w2o[0][0] + n.y * in.w2o[1][0]) + n.z * in.w2o[2][0];
+  r.y = (n.x * in.w2o[0][1] + n.y * in.w2o[1][1]) + n.z * in.w2o[2][1];
+  r.z = (n.x * in.w2o[0][2] + n.y * in.w2o[1][2]) + n.z * in.w2o[2][2];
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Ray / triangle and ray / box (the part the reference leaves to the Vulkan driver,
+// raytrace.rgen:64-75 traceRayEXT).  Explicit fmaf; see DESIGN.md section 3.
+// ------------------------------------------------------------------------------------------
+inline float fdot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+inline V3 fcross(V3 a, V3 b)
+{
+  return v3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+// Returns true when the ray hits the triangle's interior; t,u,v by one IEEE division.
+inline bool isect_tri(V3 o, V3 d, const Tri& tr, float& t, float& u, float& v)
+{
+  V3 pvec = fcross(d, tr.e2);
+  float det = fdot(tr.e1, pvec);
+  V3 tvec = o - tr.v0;
+  float U = fdot(tvec, pvec);
+  V3 qvec = fcross(tvec, tr.e1);
+  float V = fdot(d, qvec);
+  float T = fdot(tr.e2, qvec);
+  bool ok;
+  if(det > 0.0f)
+    ok = (U >= 0.0f) && (V >= 0.0f) && (U + V <= det);
+  else if(det < 0.0f)
+    ok = (U <= 0.0f) && (V <= 0.0f) && (U + V >= det);
+  else
+    ok = false;
+  if(!ok)
+    return false;
+  float inv = 1.0f / det;
+  t = T * inv;
+  u = U * inv;
+  v = V * inv;
+  return true;
+}
+
+struct RayInv
+{
+  V3 o, id;  // origin, 1/direction with |d| clamped away from zero
+};
+inline float safe_inv(float d)
+{
+  const float tiny = 1e-20f;
+  float dd = (fabsf(d) < tiny) ? copysignf(tiny, d) : d;
+  return 1.0f / dd;
+}
+// Conservative slab test (far side padded, Ize 2013): true if [tnear,tfar] overlaps [tmin,tmax].
+inline bool isect_box(const RayInv& r, const Aabb& b, float tmin, float tmax, float& tnear)
+{
+  float t0x = (b.lo[0] - r.o.x) * r.id.x, t1x = (b.hi[0] - r.o.x) * r.id.x;
+  float t0y = (b.lo[1] - r.o.y) * r.id.y, t1y = (b.hi[1] - r.o.y) * r.id.y;
+  float t0z = (b.lo[2] - r.o.z) * r.id.z, t1z = (b.hi[2] - r.o.z) * r.id.z;
+  float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+  float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  tnear = tn;
+  return tn <= tf * 1.0000004f;
+}
+
+struct Hit
+{
+  float t, u, v;
+  int32_t tri;  // index into scene.tris (== gid), -1 = miss
+};
+
+// accept rule shared by brute force and BVH: smallest t in (tmin, tmax); ties -> smallest gid
+inline void consider(const Tri& tr, V3 o, V3 d, float tmin, Hit& best, Counters& c)
+{
+  float t, u, v;
+  c.tris_tested++;
+  if(!isect_tri(o, d, tr, t, u, v))
+    return;
+  if(!(t > tmin))
+    return;
+  if(t < best.t || (t == best.t && (int32_t)tr.gid < best.tri))
+  {
+    best.t = t; best.u = u; best.v = v; best.tri = (int32_t)tr.gid;
+  }
+}
+
+Hit closest_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+{
+  Hit best{tmax, 0, 0, -1};
+  // tmax exclusive: a hit needs t < tmax; emulate by starting best.t = tmax with tri = -1
+  // (tie rule "gid < -1" never holds, so t == tmax is rejected).
+  for(const Tri& tr : s.tris)
+    consider(tr, o, d, tmin, best, c);
+  return best;
+}
+bool any_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+{
+  for(const Tri& tr : s.tris)
+  {
+    float t, u, v;
+    c.tris_tested++;
+    if(isect_tri(o, d, tr, t, u, v) && t > tmin && t < tmax)
+      return true;
+  }
+  return false;
+}
+
+Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+{
+  Hit best{tmax, 0, 0, -1};
+  if(s.tris.empty())
+    return best;
+  RayInv r{o, v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z))};
+  int32_t stack[256];
+  int sp = 0;
+  int32_t cur = s.rootIsLeaf ? ~0 : 0;
+  for(;;)
+  {
+    if(cur < 0)
+    {
+      const BvhLeaf& lf = s.leaves[~cur];
+      for(uint32_t k = 0; k < lf.count; k++)
+        consider(s.tris[s.triOrder[lf.first + k]], o, d, tmin, best, c);
+    }
+    else
+    {
+      const BvhNode& n = s.nodes[cur];
+      c.nodes_visited++;
+      float tn0, tn1;
+      bool h0 = isect_box(r, n.box[0], tmin, best.t, tn0);
+      bool h1 = isect_box(r, n.box[1], tmin, best.t, tn1);
+      if(h0 && h1)
+      {
+        int nearI = (tn1 < tn0) ? 1 : 0;
+        stack[sp++] = n.child[1 - nearI];
+        cur = n.child[nearI];
+        continue;
+      }
+      if(h0) { cur = n.child[0]; continue; }
+      if(h1) { cur = n.child[1]; continue; }
+    }
+    if(sp == 0)
+      break;
+    cur = stack[--sp];
+  }
+  return best;
+}
+bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+{
+  if(s.tris.empty())
+    return false;
+  RayInv r{o, v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z))};
+  int32_t stack[256];
+  int sp = 0;
+  int32_t cur = s.rootIsLeaf ? ~0 : 0;
+  for(;;)
+  {
+    if(cur < 0)
+    {
+      const BvhLeaf& lf = s.leaves[~cur];
+      for(uint32_t k = 0; k < lf.count; k++)
+      {
+        float t, u, v;
+        c.tris_tested++;
+        if(isect_tri(o, d, s.tris[s.triOrder[lf.first + k]], t, u, v) && t > tmin && t < tmax)
+          return true;
+      }
+    }
+    else
+    {
+      const BvhNode& n = s.nodes[cur];
+      c.nodes_visited++;
+      float tn0, tn1;
+      bool h0 = isect_box(r, n.box[0], tmin, tmax, tn0);
+      bool h1 = isect_box(r, n.box[1], tmin, tmax, tn1);
+      if(h0 && h1)
+      {
+        int nearI = (tn1 < tn0) ? 1 : 0;
+        stack[sp++] = n.child[1 - nearI];
+        cur = n.child[nearI];
+        continue;
+      }
+      if(h0) { cur = n.child[0]; continue; }
+      if(h1) { cur = n.child[1]; continue; }
+    }
+    if(sp == 0)
+      break;
+    cur = stack[--sp];
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// Full-sweep SAH BVH2, <= maxLeaf triangles per leaf (SURVEY 8d canonical tree).
+// ------------------------------------------------------------------------------------------
+struct Builder
+{
+  orc_scene& s;
+  uint32_t maxLeaf;
+  std::vector<Aabb> tb;       // per-triangle bounds
+  std::vector<V3> cen;        // per-triangle centroid
+  std::vector<float> rightArea;
+  explicit Builder(orc_scene& sc, uint32_t ml) : s(sc), maxLeaf(ml) {}
+
+  static void grow(Aabb& a, const Aabb& b)
+  {
+    for(int k = 0; k < 3; k++) { a.lo[k] = fminf(a.lo[k], b.lo[k]); a.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+  }
+  static Aabb empty()
+  {
+    Aabb a;
+    for(int k = 0; k < 3; k++) { a.lo[k] = INFINITY; a.hi[k] = -INFINITY; }
+    return a;
+  }
+  static float area(const Aabb& a)
+  {
+    float dx = a.hi[0] - a.lo[0], dy = a.hi[1] - a.lo[1], dz = a.hi[2] - a.lo[2];
+    if(!(dx >= 0) || !(dy >= 0) || !(dz >= 0))
+      return 0.f;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+  }
+  Aabb boundsOf(uint32_t first, uint32_t count)
+  {
+    Aabb a = empty();
+    for(uint32_t k = 0; k < count; k++) grow(a, tb[s.triOrder[first + k]]);
+    return a;
+  }
+  // returns child ref; depth tracking for stats
+  int32_t build(uint32_t first, uint32_t count, const Aabb& box, uint32_t depth, double& cost)
+  {
+    s.maxDepth = std::max(s.maxDepth, depth);
+    float pa = area(box);
+    auto makeLeaf = [&]() {
+      s.leaves.push_back(BvhLeaf{first, count});
+      cost = (double)count;  // intersect cost 1 per triangle
+      return (int32_t) ~(int32_t)(s.leaves.size() - 1);
+    };
+    if(count == 1)
+      return makeLeaf();
+    // full sweep over the three axes
+    float bestCost = INFINITY;
+    int bestAxis = -1;
+    uint32_t bestSplit = 0;
+    uint32_t* ord = &s.triOrder[first];
+    for(int axis = 0; axis < 3; axis++)
+    {
+      std::sort(ord, ord + count, [&](uint32_t a, uint32_t b) {
+        float ca = (&cen[a].x)[axis], cb = (&cen[b].x)[axis];
+        return ca < cb || (ca == cb && a < b);
+      });
+      Aabb acc = empty();
+      for(uint32_t k = count - 1; k > 0; k--)
+      {
+        grow(acc, tb[ord[k]]);
+        rightArea[k] = area(acc);
+      }
+      acc = empty();
+      for(uint32_t k = 1; k < count; k++)
+      {
+        grow(acc, tb[ord[k - 1]]);
+        float cst = area(acc) * (float)k + rightArea[k] * (float)(count - k);
+        if(cst < bestCost) { bestCost = cst; bestAxis = axis; bestSplit = k; }
+      }
+    }
+    float splitCost = (pa > 0.f) ? 1.0f + bestCost / pa : INFINITY;
+    if(count <= maxLeaf && !(splitCost < (float)count))
+      return makeLeaf();
+    if(bestAxis < 0 || !(bestCost < INFINITY)) { bestAxis = 0; bestSplit = count / 2; }
+    std::sort(ord, ord + count, [&](uint32_t a, uint32_t b) {
+      float ca = (&cen[a].x)[bestAxis], cb = (&cen[b].x)[bestAxis];
+      return ca < cb || (ca == cb && a < b);
+    });
+    int32_t me = (int32_t)s.nodes.size();
+    s.nodes.push_back(BvhNode{});
+    Aabb b0 = boundsOf(first, bestSplit);
+    Aabb b1 = boundsOf(first + bestSplit, count - bestSplit);
+    double c0 = 0, c1 = 0;
+    int32_t ch0 = build(first, bestSplit, b0, depth + 1, c0);
+    int32_t ch1 = build(first + bestSplit, count - bestSplit, b1, depth + 1, c1);
+    BvhNode& n = s.nodes[me];
+    n.box[0] = b0; n.box[1] = b1; n.child[0] = ch0; n.child[1] = ch1;
+    double p = pa > 0 ? pa : 1.0;
+    cost = 1.0 + (area(b0) * c0 + area(b1) * c1) / p;
+    return me;
+  }
+  void run()
+  {
+    uint32_t n = (uint32_t)s.tris.size();
+    s.nodes.clear(); s.leaves.clear(); s.triOrder.resize(n); s.maxDepth = 0;
+    tb.resize(n); cen.resize(n); rightArea.resize(n + 1);
+    Aabb all = empty();
+    for(uint32_t i = 0; i < n; i++)
+    {
+      const Tri& t = s.tris[i];
+      V3 a = t.v0, b = t.v0 + t.e1, c = t.v0 + t.e2;
+      Aabb bb;
+      bb.lo[0] = fminf(a.x, fminf(b.x, c.x)); bb.hi[0] = fmaxf(a.x, fmaxf(b.x, c.x));
+      bb.lo[1] = fminf(a.y, fminf(b.y, c.y)); bb.hi[1] = fmaxf(a.y, fmaxf(b.y, c.y));
+      bb.lo[2] = fminf(a.z, fminf(b.z, c.z)); bb.hi[2] = fmaxf(a.z, fmaxf(b.z, c.z));
+      tb[i] = bb;
+      cen[i] = v3(0.5f * (bb.lo[0] + bb.hi[0]), 0.5f * (bb.lo[1] + bb.hi[1]), 0.5f * (bb.lo[2] + bb.hi[2]));
+      s.triOrder[i] = i;
+      grow(all, bb);
+    }
+    s.rootIsLeaf = false;
+    if(n == 0)
+      return;
+    double cost = 0;
+    int32_t root = build(0, n, all, 0, cost);
+    s.sahCost = cost;
+    if(root < 0)
+      s.rootIsLeaf = true;  // whole scene in leaf 0
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Texture fetch: bilinear, REPEAT, LOD 0 (hello_vulkan.cpp:448-454; rchit has no derivatives)
+// ------------------------------------------------------------------------------------------
+struct V4 { float x, y, z, w; };
+inline int wrapi(int i, int n)
+{
+  int m = i % n;
+  return m < 0 ? m + n : m;
+}
+inline V4 texel(const orc_scene& s, const Tex& tx, int x, int y)
+{
+  const uint8_t* p = &tx.rgba[((size_t)y * tx.w + x) * 4];
+  V4 r;
+  if(tx.srgb) { r.x = s.srgb_lut[p[0]]; r.y = s.srgb_lut[p[1]]; r.z = s.srgb_lut[p[2]]; }
+  else { r.x = (float)p[0] / 255.0f; r.y = (float)p[1] / 255.0f; r.z = (float)p[2] / 255.0f; }
+  r.w = (float)p[3] / 255.0f;
+  return r;
+}
+V4 sampleTex(const orc_scene& s, int texIndex, float u, float v, Counters& c)
+{
+  c.tex_taps++;
+  if(s.tex.empty() || texIndex < 0 || texIndex >= (int)s.tex.size())
+    return V4{1, 1, 1, 1};  // 1x1 white dummy (hello_vulkan.cpp:468-472)
+  const Tex& tx = s.tex[texIndex];
+  float fx = u * (float)tx.w - 0.5f;
+  float fy = v * (float)tx.h - 0.5f;
+  if(!(fabsf(fx) < 1.0e9f)) fx = 0.0f;
+  if(!(fabsf(fy) < 1.0e9f)) fy = 0.0f;
+  float flx = floorf(fx), fly = floorf(fy);
+  float ax = fx - flx, ay = fy - fly;
+  int x0 = wrapi((int)flx, (int)tx.w), x1 = wrapi((int)flx + 1, (int)tx.w);
+  int y0 = wrapi((int)fly, (int)tx.h), y1 = wrapi((int)fly + 1, (int)tx.h);
+  V4 t00 = texel(s, tx, x0, y0), t10 = texel(s, tx, x1, y0);
+  V4 t01 = texel(s, tx, x0, y1), t11 = texel(s, tx, x1, y1);
+  float bx = 1.0f - ax, by = 1.0f - ay;
+  V4 r;
+  r.x = (t00.x * bx + t10.x * ax) * by + (t01.x * bx + t11.x * ax) * ay;
+  r.y = (t00.y * bx + t10.y * ax) * by + (t01.y * bx + t11.y * ax) * ay;
+  r.z = (t00.z * bx + t10.z * ax) * by + (t01.z * bx + t11.z * ax) * ay;
+  r.w = (t00.w * bx + t10.w * ax) * by + (t01.w * bx + t11.w * ax) * ay;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// gltf.glsl:26-154
+// ------------------------------------------------------------------------------------------
+struct ShadeCtx
+{
+  const orc_scene& s;
+  Counters& c;
+};
+inline V3 matBase(const GltfPBRMaterial& m) { return v3(m.pbrBaseColorFactor[0], m.pbrBaseColorFactor[1], m.pbrBaseColorFactor[2]); }
+// gltf.glsl:26-32
+V3 pbrGetBaseColor(ShadeCtx& cx, const GltfPBRMaterial& mat, float tu, float tv)
+{
+  V3 color = matBase(mat);
+  if(mat.pbrBaseColorTexture > -1)
+  {
+    V4 t = sampleTex(cx.s, mat.pbrBaseColorTexture, tu, tv, cx.c);
+    color = color * v3(t.x, t.y, t.z);
+  }
+  return color;
+}
+// gltf.glsl:34-45
+void pbrGetMetallicRoughness(ShadeCtx& cx, const GltfPBRMaterial& mat, float tu, float tv, float& metallic, float& roughness)
+{
+  metallic = mat.metallicFactor;
+  roughness = mat.roughnessFactor;
+  if(mat.metallicRoughnessTexture > -1)
+  {
+    V4 t = sampleTex(cx.s, mat.metallicRoughnessTexture, tu, tv, cx.c);
+    roughness *= t.y;
+    metallic *= t.z;
+  }
+}
+// gltf.glsl:55-66
+float getNDF_GGXTR(V3 N, V3 H, float alpha)
+{
+  float a2 = alpha * alpha;
+  float NH = dot(N, H);
+  if(NH <= 0.0f)
+    return 0.0f;
+  float NH2 = NH * NH;
+  float d = NH2 * (a2 - 1.0f) + 1.0f;
+  return a2 * M_INV_PI_F / (d * d + 1e-4f);
+}
+// gltf.glsl:68-71
+float getG_SchlickGGX(float NV, float k) { return NV / (NV * (1.0f - k) + k); }
+// gltf.glsl:73-78
+float getG_Smith(V3 N, V3 V, V3 L, float k)
+{
+  float NV = fabsf(dot(N, V));
+  float NL = fabsf(dot(N, L));
+  return getG_SchlickGGX(NV, k) * getG_SchlickGGX(NL, k);
+}
+// gltf.glsl:80-83
+V3 getF_Schlick(V3 H, V3 V, V3 F0)
+{
+  return F0 + (v3(1.0f) - F0) * vk_pow5(1.0f - fabsf(dot(H, V)));
+}
+// gltf.glsl:85-96
+V3 getSpecularBRDF_Cook_Torrance(V3 N, V3 H, V3 V, V3 L, V3 F0, float roughness)
+{
+  float alpha = roughness * roughness;
+  float k = (roughness + 1.0f) * (roughness + 1.0f) / 8.0f;
+  float D = getNDF_GGXTR(N, H, alpha);
+  float G = getG_Smith(N, V, L, k);
+  V3 F = getF_Schlick(H, V, F0);
+  float down = 4.0f * fabsf(dot(V, N)) * fabsf(dot(L, N)) + 1e-4f;
+  return D * F * G / down;
+}
+// gltf.glsl:98-109
+V3 getSpecularBRDF_over_pdf_Cook_Torrance(V3 N, V3 H, V3 V, V3 L, V3 F0, float roughness, float ratio)
+{
+  float k = (roughness + 1.0f) * (roughness + 1.0f) / 8.0f;
+  float pdf = (1.0f - ratio) * dot(N, H) / (4.0f * dot(L, H) + 1e-4f);
+  float G = getG_Smith(N, V, L, k);
+  V3 F = getF_Schlick(H, V, F0);
+  float down = 4.0f * fabsf(dot(V, N)) * fabsf(dot(L, N)) + 1e-4f;
+  return (F * G / down) / pdf;
+}
+// gltf.glsl:111-134 (pbrGetEmissive at :116 is dead: its result is unused)
+V3 computePBR_BRDF(ShadeCtx& cx, V3 N, V3 V, V3 L, V3 H, const GltfPBRMaterial& mat, float tu, float tv)
+{
+  V3 baseColor = pbrGetBaseColor(cx, mat, tu, tv);
+  float metalness, roughness;
+  pbrGetMetallicRoughness(cx, mat, tu, tv, metalness, roughness);
+  V3 F0 = v3(0.04f);
+  F0 = glsl_mix(F0, baseColor, metalness);
+  V3 F = getF_Schlick(H, V, F0);
+  V3 f_cook_torrance = getSpecularBRDF_Cook_Torrance(N, H, V, L, F0, roughness);
+  V3 kD = v3(1.0f) - F;
+  kD = kD * (1.0f - metalness);
+  V3 f_lambert = baseColor * M_INV_PI_F;
+  V3 diffuse = kD * f_lambert;
+  return diffuse + f_cook_torrance;
+}
+// gltf.glsl:136-154.  Non-point lights: returns 0 and leaves Li/cosTheta undefined in the
+// GLSL; here Li = 0, cosTheta = 0.
+V3 directLight(ShadeCtx& cx, const GltfLight& light, V3 P, V3 N, V3 V, const GltfPBRMaterial& mat, float tu, float tv, V3& Li, float& cosTheta)
+{
+  Li = v3(0.0f);
+  cosTheta = 0.0f;
+  if(light.type == 0)
+  {
+    V3 Ldir = v3(light.position[0], light.position[1], light.position[2]) - P;
+    float d = length(Ldir);
+    V3 L = Ldir / d;
+    V3 H = normalize(L + V);
+    float attenuation = d * d;
+    Li = v3(light.color[0], light.color[1], light.color[2]) * light.intensity / attenuation;
+    cosTheta = glsl_max(dot(L, N), 0.0f);
+    if(cosTheta > 0.0f)
+      return computePBR_BRDF(cx, N, V, L, H, mat, tu, tv);
+  }
+  return v3(0.0f);
+}
+
+// raycommon.glsl:8-19
+struct Payload
+{
+  V3 hitValue;
+  uint32_t seed;
+  uint32_t depth;
+  V3 rayOrigin, rayDirection, weight;
+  bool isSpecular;
+  float lightDist;
+  V3 shadowRayDir;
+};
+
+// Surface attributes after interpolation/transform (raytrace.rchit:68-79).
+struct Surface
+{
+  V3 worldPos, worldNrm, worldTag, worldBin;
+  float tu, tv;
+};
+
+// raytrace.rchit:81-219, everything after the attribute fetch.
+void shadeSurface(ShadeCtx& cx, const PushConstantRay& pc, const GltfPBRMaterial& mat, const Surface& sf, V3 worldRayDir, Payload& prd)
+{
+  cx.c.hits++;
+  V3 emittance = v3(0.0f);
+  if(prd.depth == 0 || prd.isSpecular)
+  {
+    emittance = v3(mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]);
+    if(mat.emissiveTexture > -1)
+    {
+      V4 t = sampleTex(cx.s, mat.emissiveTexture, sf.tu, sf.tv, cx.c);
+      emittance = emittance * v3(t.x, t.y, t.z);
+    }
+  }
+  V3 tangent = sf.worldTag, binormal = sf.worldBin;
+  V3 texNormal = sf.worldNrm;
+  // rchit:98 ffnormal is computed and never used.
+  if(mat.normalTexture > -1)
+  {
+    V4 t = sampleTex(cx.s, mat.normalTexture, sf.tu, sf.tv, cx.c);
+    texNormal = normalize(v3(t.x, t.y, t.z) * 2.0f - v3(1.0f));
+    // TBN * n, TBN = mat3(tangent, binormal, worldNrm) (rchit:99,103)
+    texNormal = normalize(tangent * texNormal.x + binormal * texNormal.y + sf.worldNrm * texNormal.z);
+    createCoordinateSystem(texNormal, tangent, binormal);
+  }
+  V3 baseColor = pbrGetBaseColor(cx, mat, sf.tu, sf.tv);
+  float metalness, roughness;
+  pbrGetMetallicRoughness(cx, mat, sf.tu, sf.tv, metalness, roughness);
+
+  V3 rayOrigin = sf.worldPos;
+  V3 rayDirection;
+  float pdf;
+  V3 BRDF;
+  V3 V = normalize(-worldRayDir);
+  V3 N = texNormal;
+
+  float ratio = 0.5f * (1.0f - metalness);
+  roughness = glsl_clamp(roughness, 0.01f, 0.99f);
+  metalness = glsl_clamp(metalness, 0.01f, 0.99f);
+  float r1 = rnd(prd.seed);
+  if(r1 < ratio)
+  {
+    cx.c.diffuse_hits++;
+    prd.isSpecular = false;
+    int random_index = (int)(rnd(prd.seed) * (float)pc.lightsCount);
+    const GltfLight& light = cx.s.lights[random_index];
+    V3 lightDir = v3(light.position[0], light.position[1], light.position[2]) - sf.worldPos;
+    float lightDistance = length(lightDir);
+    V3 L = normalize(lightDir);
+    prd.lightDist = lightDistance;
+    prd.shadowRayDir = L;
+    if(dot(L, texNormal) <= 0)
+      emittance = emittance + v3(0.0f);
+    else
+    {
+      V3 Li;
+      float cosTheta;
+      V3 brdf = directLight(cx, light, sf.worldPos, texNormal, V, mat, sf.tu, sf.tv, Li, cosTheta);
+      emittance = emittance + (float)pc.lightsCount * brdf * Li * cosTheta;
+    }
+    rayDirection = normalize(samplingHemisphere(prd.seed, tangent, binormal, texNormal));
+    pdf = ratio * dot(rayDirection, texNormal) * M_INV_PI_F;
+    BRDF = (1.0f - metalness) * baseColor * M_INV_PI_F;
+  }
+  else
+  {
+    prd.isSpecular = true;
+    float alpha = roughness * roughness;
+    V3 h = samplingNDF_GGXTR(prd.seed, alpha * alpha);
+    V3 H = normalize(tangent * h.x + binormal * h.y + texNormal * h.z);
+    V3 L = normalize(glsl_reflect(-V, H));
+    rayDirection = L;
+    V3 F0 = v3(0.04f);
+    F0 = glsl_mix(F0, baseColor, metalness);
+    pdf = 1.0f;
+    BRDF = getSpecularBRDF_over_pdf_Cook_Torrance(N, H, V, L, F0, roughness, ratio);
+  }
+  float cosTheta = dot(rayDirection, texNormal);
+  prd.rayOrigin = rayOrigin;
+  prd.rayDirection = rayDirection;
+  prd.hitValue = emittance;
+  prd.weight = BRDF * cosTheta / pdf;
+}
+
+// raytrace.rchit:34-79 attribute fetch + interpolation, then shadeSurface.
+void closestHitShader(ShadeCtx& cx, const PushConstantRay& pc, const Hit& hit, V3 worldRayDir, Payload& prd)
+{
+  const orc_scene& s = cx.s;
+  const Tri& tr = s.tris[hit.tri];
+  const Instance& in = s.inst[tr.inst];
+  const vkrt_prim_mesh& pinfo = s.pm[in.primMesh];
+  uint32_t indexOffset = pinfo.firstIndex + 3 * tr.prim;
+  uint32_t vertexOffset = pinfo.vertexOffset;
+  uint32_t matIndex = (uint32_t)std::max(0, pinfo.materialIndex);
+  uint32_t i0 = s.idx[indexOffset + 0] + vertexOffset;
+  uint32_t i1 = s.idx[indexOffset + 1] + vertexOffset;
+  uint32_t i2 = s.idx[indexOffset + 2] + vertexOffset;
+  V3 b = v3(1.0f - hit.u - hit.v, hit.u, hit.v);
+  V3 pos = s.pos[i0] * b.x + s.pos[i1] * b.y + s.pos[i2] * b.z;
+  Surface sf;
+  sf.worldPos = xformPoint(in, pos);
+  V3 nrm = normalize(s.nrm[i0] * b.x + s.nrm[i1] * b.y + s.nrm[i2] * b.z);
+  sf.worldNrm = normalize(xformNormal(in, nrm));
+  V3 tg0 = v3(s.tan4[4 * i0], s.tan4[4 * i0 + 1], s.tan4[4 * i0 + 2]);
+  V3 tg1 = v3(s.tan4[4 * i1], s.tan4[4 * i1 + 1], s.tan4[4 * i1 + 2]);
+  V3 tg2 = v3(s.tan4[4 * i2], s.tan4[4 * i2 + 1], s.tan4[4 * i2 + 2]);
+  V3 tag = normalize(tg0 * b.x + tg1 * b.y + tg2 * b.z);
+  V3 worldTag = normalize(xformNormal(in, tag));
+  worldTag = normalize(worldTag - dot(worldTag, sf.worldNrm) * sf.worldNrm);
+  sf.worldTag = worldTag;
+  sf.worldBin = s.tan4[4 * i0 + 3] * cross(sf.worldNrm, worldTag);
+  sf.tu = (s.uv2[2 * i0] * b.x + s.uv2[2 * i1] * b.y) + s.uv2[2 * i2] * b.z;
+  sf.tv = (s.uv2[2 * i0 + 1] * b.x + s.uv2[2 * i1 + 1] * b.y) + s.uv2[2 * i2 + 1] * b.z;
+  shadeSurface(cx, pc, s.mats[matIndex], sf, worldRayDir, prd);
+}
+
+// raytrace.rmiss:11-19
+inline void missShader(const PushConstantRay& pc, Payload& prd)
+{
+  if(prd.depth == 0)
+    prd.hitValue = v3(pc.clearColor[0], pc.clearColor[1], pc.clearColor[2]) * 0.8f;
+  else
+    prd.hitValue = v3(0.01f);
+  prd.depth = 100;
+}
+
+inline void mat4MulVec4(const vkrt_mat4& M, const float v[4], float out[4])
+{
+  for(int i = 0; i < 4; i++)
+    out[i] = ((M.m[0 + i] * v[0] + M.m[4 + i] * v[1]) + M.m[8 + i] * v[2]) + M.m[12 + i] * v[3];
+}
+
+struct PathLog  // optional per-segment trace of one pixel (debug / parity localisation)
+{
+  std::vector<float>* out;
+};
+
+// raytrace.rgen:24-146 for one pixel.  Returns the value stored to the image (rgba).
+void rayGen(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms& uni, uint32_t seedArg, uint32_t flags,
+            uint32_t x, uint32_t y, uint32_t W, uint32_t H, bool useBvh, float* pixel /* in: old, out: new */,
+            Counters& c, PathLog* log)
+{
+  ShadeCtx cx{s, c};
+  c.pixels++;
+  Payload prd;
+  memset(&prd, 0, sizeof(prd));
+  uint32_t index = (flags & VKRT_TRACE_SEED_INDEX_ROW_MAJOR) ? (y * W + x) : (y * x + x);  // rgen:27
+  prd.seed = tea(index, seedArg);
+  V3 hitValues = v3(0.0f);
+  const float o4[4] = {0, 0, 0, 1};
+  float origin[4];
+  mat4MulVec4(uni.viewInverse, o4, origin);
+  const float tMin = 0.001f, tMax = 10000.0f;
+  for(int smpl = 0; smpl < pc.samples; smpl++)
+  {
+    float r1 = rnd(prd.seed);
+    float r2 = rnd(prd.seed);
+    float jx = pc.frame == 0 ? 0.5f : r1, jy = pc.frame == 0 ? 0.5f : r2;
+    float pcx = (float)x + jx, pcy = (float)y + jy;
+    float inU = pcx / (float)W, inV = pcy / (float)H;
+    float dx = inU * 2.0f - 1.0f, dy = inV * 2.0f - 1.0f;
+    const float d4[4] = {dx, dy, 1, 1};
+    float target[4];
+    mat4MulVec4(uni.projInverse, d4, target);
+    V3 tn = normalize(v3(target[0], target[1], target[2]));
+    const float t4[4] = {tn.x, tn.y, tn.z, 0};
+    float direction[4];
+    mat4MulVec4(uni.viewInverse, t4, direction);
+
+    prd.hitValue = v3(0.0f);
+    prd.rayOrigin = v3(origin[0], origin[1], origin[2]);
+    prd.rayDirection = v3(direction[0], direction[1], direction[2]);
+    prd.depth = 0;
+    prd.weight = v3(0.0f);
+    V3 curWeight = v3(1.0f);
+    V3 hitValue = v3(0.0f);
+    for(; prd.depth < (uint32_t)pc.depth; prd.depth++)
+    {
+      c.rays_closest++;
+      V3 rd = prd.rayDirection;
+      Hit h = useBvh ? closest_bvh(s, prd.rayOrigin, rd, tMin, tMax, c) : closest_brute(s, prd.rayOrigin, rd, tMin, tMax, c);
+      if(log)
+      {
+        float rec[8] = {(float)prd.depth, (float)h.tri, h.t, h.u, h.v, 0, 0, 0};
+        log->out->insert(log->out->end(), rec, rec + 8);
+      }
+      if(h.tri >= 0)
+        closestHitShader(cx, pc, h, rd, prd);
+      else
+        missShader(pc, prd);
+      bool shadowHit = false;
+      if(!prd.isSpecular && prd.depth != 100)  // rgen:79
+      {
+        c.rays_shadow++;
+        float smax = prd.lightDist - 0.1f;
+        shadowHit = useBvh ? any_bvh(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c)
+                           : any_brute(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c);
+      }
+      if(!shadowHit)  // rgen:99-102
+      {
+        V3 q = prd.hitValue * curWeight;
+        hitValue = hitValue + v3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
+      }
+      if(log)
+      {
+        float rec[8] = {-1.0f, shadowHit ? 1.0f : 0.0f, prd.hitValue.x, prd.hitValue.y, prd.hitValue.z, prd.weight.x, prd.weight.y, prd.weight.z};
+        log->out->insert(log->out->end(), rec, rec + 8);
+      }
+      curWeight = curWeight * prd.weight;  // rgen:115
+    }
+    hitValues = hitValues + hitValue;
+  }
+  V3 res = hitValues / (float)pc.samples;  // rgen:120
+  if(pc.frame > 0)                          // rgen:136-141
+  {
+    float a = 1.0f / (float)(pc.frame + 1);
+    V3 old = v3(pixel[0], pixel[1], pixel[2]);
+    V3 m = glsl_mix(old, res, a);
+    pixel[0] = m.x; pixel[1] = m.y; pixel[2] = m.z; pixel[3] = 1.0f;
+  }
+  else
+  {
+    pixel[0] = res.x; pixel[1] = res.y; pixel[2] = res.z; pixel[3] = 1.0f;
+  }
+}
+
+thread_local char g_err[256] = "";
+
+}  // namespace
+
+// =============================================================================================
+// C interface for the Python test harness (ctypes)
+// =============================================================================================
+extern "C" {
+
+const char* orc_last_error() { return g_err; }
+
+uint32_t orc_tea(uint32_t a, uint32_t b) { return tea(a, b); }
+uint32_t orc_lcg(uint32_t* state) { return lcg(*state); }
+float orc_rnd(uint32_t* state) { return rnd(*state); }
+
+orc_scene* orc_scene_create(const vkrt_scene_desc* d)
+{
+  if(!d || d->struct_size != sizeof(vkrt_scene_desc))
+  {
+    snprintf(g_err, sizeof g_err, "bad scene desc");
+    return nullptr;
+  }
+  if(d->material_count == 0 || d->light_count == 0)
+  {
+    snprintf(g_err, sizeof g_err, "scene needs >=1 material and >=1 light");
+    return nullptr;
+  }
+  orc_scene* s = new orc_scene();
+  s->pos.resize(d->vertex_count); s->nrm.resize(d->vertex_count);
+  memcpy(s->pos.data(), d->positions, sizeof(float) * 3 * d->vertex_count);
+  memcpy(s->nrm.data(), d->normals, sizeof(float) * 3 * d->vertex_count);
+  s->tan4.assign(d->tangents, d->tangents + 4 * (size_t)d->vertex_count);
+  s->uv2.assign(d->texcoords0, d->texcoords0 + 2 * (size_t)d->vertex_count);
+  s->idx.assign(d->indices, d->indices + d->index_count);
+  s->pm.assign(d->prim_meshes, d->prim_meshes + d->prim_mesh_count);
+  s->mats.assign(d->materials, d->materials + d->material_count);
+  s->lights.assign(d->lights, d->lights + d->light_count);
+  for(int i = 0; i < 256; i++)
+  {
+    float c = (float)i / 255.0f;
+    s->srgb_lut[i] = (c <= 0.04045f) ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+  }
+  for(uint32_t t = 0; t < d->texture_count; t++)
+  {
+    Tex tx;
+    tx.w = d->textures[t].width; tx.h = d->textures[t].height; tx.srgb = d->textures[t].is_srgb != 0;
+    tx.rgba.assign(d->textures[t].rgba8, d->textures[t].rgba8 + (size_t)tx.w * tx.h * 4);
+    s->tex.push_back(std::move(tx));
+  }
+  uint32_t gid = 0;
+  for(uint32_t n = 0; n < d->node_count; n++)
+  {
+    Instance in;
+    const float* m = d->nodes[n].worldMatrix;
+    for(int r = 0; r < 3; r++)
+      for(int c = 0; c < 4; c++)
+        in.o2w[r][c] = m[c * 4 + r];
+    invert3x3(in.o2w, in.w2o);
+    in.primMesh = d->nodes[n].primMesh;
+    if(in.primMesh < 0 || (uint32_t)in.primMesh >= d->prim_mesh_count)
+    {
+      snprintf(g_err, sizeof g_err, "node %u: primMesh out of range", n);
+      delete s;
+      return nullptr;
+    }
+    s->inst.push_back(in);
+    const vkrt_prim_mesh& pm = s->pm[in.primMesh];
+    for(uint32_t p = 0; p < pm.indexCount / 3; p++)
+    {
+      uint32_t i0 = s->idx[pm.firstIndex + 3 * p + 0] + pm.vertexOffset;
+      uint32_t i1 = s->idx[pm.firstIndex + 3 * p + 1] + pm.vertexOffset;
+      uint32_t i2 = s->idx[pm.firstIndex + 3 * p + 2] + pm.vertexOffset;
+      V3 a = xformPoint(in, s->pos[i0]), b = xformPoint(in, s->pos[i1]), c = xformPoint(in, s->pos[i2]);
+      Tri t;
+      t.v0 = a; t.e1 = b - a; t.e2 = c - a;
+      t.gid = gid++; t.inst = n; t.prim = p;
+      s->tris.push_back(t);
+    }
+  }
+  return s;
+}
+void orc_scene_destroy(orc_scene* s) { delete s; }
+uint32_t orc_triangle_count(const orc_scene* s) { return (uint32_t)s->tris.size(); }
+
+// Full-sweep SAH BVH2 with <= max_leaf triangles per leaf (canonical accounting tree).
+int orc_build_bvh(orc_scene* s, uint32_t max_leaf)
+{
+  Builder b(*s, max_leaf < 1 ? 1 : max_leaf);
+  b.run();
+  return 0;
+}
+void orc_bvh_info(const orc_scene* s, uint32_t* nodes, uint32_t* leaves, uint32_t* maxDepth, double* sah)
+{
+  *nodes = (uint32_t)s->nodes.size(); *leaves = (uint32_t)s->leaves.size(); *maxDepth = s->maxDepth; *sah = s->sahCost;
+}
+// World-space triangles as (v0,e1,e2) float[9] + (gid,inst,prim) u32[3], for builder tests.
+void orc_get_triangles(const orc_scene* s, float* v9, uint32_t* ids3)
+{
+  for(size_t i = 0; i < s->tris.size(); i++)
+  {
+    const Tri& t = s->tris[i];
+    float* o = v9 + 9 * i;
+    o[0] = t.v0.x; o[1] = t.v0.y; o[2] = t.v0.z; o[3] = t.e1.x; o[4] = t.e1.y; o[5] = t.e1.z; o[6] = t.e2.x; o[7] = t.e2.y; o[8] = t.e2.z;
+    ids3[3 * i] = t.gid; ids3[3 * i + 1] = t.inst; ids3[3 * i + 2] = t.prim;
+  }
+}
+
+/* Render rows[0..nrows) of a full_w x full_h launch into the compact buffer `out`
+ * (nrows x full_w x rgba32f, in/out when pc->frame > 0).  use_bvh 0 = brute force.
+ * threads <= 0: hardware concurrency.  counters (8 x u64, vkrt_counters order) optional. */
+int orc_render_rows(const orc_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, uint32_t seed, uint32_t flags,
+                    uint32_t full_w, uint32_t full_h, const uint32_t* rows, uint32_t nrows, float* out, int use_bvh, int threads,
+                    uint64_t* counters)
+{
+  if(use_bvh && s->nodes.empty() && !s->rootIsLeaf && !s->tris.empty())
+  {
+    snprintf(g_err, sizeof g_err, "BVH not built");
+    return 1;
+  }
+  if(pc->lightsCount < 0 || (uint32_t)pc->lightsCount > s->lights.size())
+  {
+    snprintf(g_err, sizeof g_err, "lightsCount out of range");
+    return 1;
+  }
+  int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  if(nt < 1) nt = 1;
+  std::atomic<uint32_t> next{0};
+  std::vector<Counters> cs(nt);
+  auto work = [&](int tid) {
+    Counters& c = cs[tid];
+    for(;;)
+    {
+      uint32_t r = next.fetch_add(1);
+      if(r >= nrows) break;
+      uint32_t y = rows[r];
+      for(uint32_t x = 0; x < full_w; x++)
+        rayGen(*s, *pc, *cam, seed, flags, x, y, full_w, full_h, use_bvh != 0, out + ((size_t)r * full_w + x) * 4, c, nullptr);
+    }
+  };
+  if(nt == 1)
+    work(0);
+  else
+  {
+    std::vector<std::thread> th;
+    for(int t = 0; t < nt; t++) th.emplace_back(work, t);
+    for(auto& t : th) t.join();
+  }
+  if(counters)
+  {
+    Counters tot;
+    for(auto& c : cs) tot.add(c);
+    counters[0] = tot.rays_closest; counters[1] = tot.rays_shadow; counters[2] = tot.hits; counters[3] = tot.diffuse_hits;
+    counters[4] = tot.tex_taps; counters[5] = tot.pixels; counters[6] = tot.nodes_visited; counters[7] = tot.tris_tested;
+  }
+  return 0;
+}
+
+/* Per-segment log of one pixel: records of 8 floats, alternating
+ * {depth, gid, t, u, v, 0,0,0} and {-1, shadowHit, hitValue.xyz, weight.xyz}. Returns count of floats. */
+int orc_pixel_log(const orc_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, uint32_t seed, uint32_t flags,
+                  uint32_t full_w, uint32_t full_h, uint32_t x, uint32_t y, int use_bvh, float* rgba_inout, float* log, int log_cap)
+{
+  std::vector<float> v;
+  PathLog pl{&v};
+  Counters c;
+  rayGen(*s, *pc, *cam, seed, flags, x, y, full_w, full_h, use_bvh != 0, rgba_inout, c, &pl);
+  int n = (int)std::min<size_t>(v.size(), (size_t)log_cap);
+  memcpy(log, v.data(), sizeof(float) * n);
+  return (int)v.size();
+}
+
+/* Closest / any hit for a batch of rays (for builder and traversal tests). */
+int orc_trace_rays(const orc_scene* s, uint32_t n, const float* o, const float* d, float tmin, float tmax, int any_hit, int use_bvh,
+                   float* t, float* u, float* v, int32_t* gid, uint64_t* counters)
+{
+  Counters c;
+  for(uint32_t i = 0; i < n; i++)
+  {
+    V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    if(any_hit)
+    {
+      bool h = use_bvh ? any_bvh(*s, ro, rd, tmin, tmax, c) : any_brute(*s, ro, rd, tmin, tmax, c);
+      gid[i] = h ? 0 : -1; t[i] = 0; u[i] = 0; v[i] = 0;
+    }
+    else
+    {
+      Hit h = use_bvh ? closest_bvh(*s, ro, rd, tmin, tmax, c) : closest_brute(*s, ro, rd, tmin, tmax, c);
+      gid[i] = h.tri; t[i] = h.t; u[i] = h.u; v[i] = h.v;
+    }
+  }
+  if(counters) { counters[6] = c.nodes_visited; counters[7] = c.tris_tested; }
+  return 0;
+}
+
+/* op: 0 sin, 1 cos, 2 sqrt, 3 a/b, 4 pow5, 5 x of normalize((a,b,0)) */
+void orc_eval_math(int op, uint32_t n, const float* a, const float* b, float* out)
+{
+  for(uint32_t i = 0; i < n; i++)
+  {
+    switch(op)
+    {
+      case 0: out[i] = vk_sin(a[i]); break;
+      case 1: out[i] = vk_cos(a[i]); break;
+      case 2: out[i] = sqrtf(a[i]); break;
+      case 3: out[i] = a[i] / b[i]; break;
+      case 4: out[i] = vk_pow5(a[i]); break;
+      default: out[i] = normalize(v3(a[i], b[i], 0.0f)).x; break;
+    }
+  }
+}
+
+/* Shading spot-evaluation for cross-checking with oracle/np_shading.py.
+ * in : per item 40 floats:
+ *   [0:3] worldPos [3:6] worldNrm [6:9] tangent [9:12] binormal [12:15] worldRayDir
+ *   [15:19] baseColorFactor [19] metallic [20] roughness [21:24] emissive
+ *   [24:27] light.position [27:30] light.color [30] intensity [31] light.type
+ *   [32] seed(bits) [33] depth(bits) [34] isSpecular(bits) [35] lightsCount(bits) [36:40] pad
+ * out: per item 20 floats:
+ *   [0:3] hitValue [3:6] rayOrigin [6:9] rayDirection [9:12] weight [12] isSpecular
+ *   [13] lightDist [14:17] shadowRayDir [17] seed(bits) [18:20] pad
+ */
+void orc_eval_shade(uint32_t n, const float* in, float* out)
+{
+  orc_scene s;
+  s.lights.resize(1);
+  Counters c;
+  ShadeCtx cx{s, c};
+  for(uint32_t i = 0; i < n; i++)
+  {
+    const float* p = in + 40 * (size_t)i;
+    float* o = out + 20 * (size_t)i;
+    Surface sf;
+    sf.worldPos = v3(p[0], p[1], p[2]); sf.worldNrm = v3(p[3], p[4], p[5]); sf.worldTag = v3(p[6], p[7], p[8]);
+    sf.worldBin = v3(p[9], p[10], p[11]); sf.tu = 0; sf.tv = 0;
+    V3 rd = v3(p[12], p[13], p[14]);
+    GltfPBRMaterial m;
+    memset(&m, 0, sizeof m);
+    for(int k = 0; k < 4; k++) m.pbrBaseColorFactor[k] = p[15 + k];
+    m.metallicFactor = p[19]; m.roughnessFactor = p[20];
+    for(int k = 0; k < 3; k++) m.emissiveFactor[k] = p[21 + k];
+    m.pbrBaseColorTexture = m.metallicRoughnessTexture = m.normalTexture = m.emissiveTexture = -1;
+    GltfLight& L = s.lights[0];
+    for(int k = 0; k < 3; k++) { L.position[k] = p[24 + k]; L.color[k] = p[27 + k]; }
+    L.intensity = p[30];
+    uint32_t bits[4];
+    memcpy(bits, p + 32, 16);
+    memcpy(&L.type, p + 31, 4);
+    PushConstantRay pc;
+    memset(&pc, 0, sizeof pc);
+    pc.lightsCount = (int32_t)bits[3];
+    Payload prd;
+    memset(&prd, 0, sizeof prd);
+    prd.seed = bits[0]; prd.depth = bits[1]; prd.isSpecular = bits[2] != 0;
+    // lightsCount may exceed 1 for the NEE scale factor; the light index is forced to 0 by
+    // evaluating with a single light whenever int(rnd*lightsCount) would pick another one.
+    int32_t lc = pc.lightsCount;
+    {
+      uint32_t probe = prd.seed;
+      float r1 = rnd(probe);
+      (void)r1;
+      uint32_t probe2 = probe;
+      int idx = (int)(rnd(probe2) * (float)lc);
+      GltfLight Lc = s.lights[0];
+      if(idx != 0) s.lights.resize((size_t)idx + 1, Lc);
+    }
+    shadeSurface(cx, pc, m, sf, rd, prd);
+    o[0] = prd.hitValue.x; o[1] = prd.hitValue.y; o[2] = prd.hitValue.z;
+    o[3] = prd.rayOrigin.x; o[4] = prd.rayOrigin.y; o[5] = prd.rayOrigin.z;
+    o[6] = prd.rayDirection.x; o[7] = prd.rayDirection.y; o[8] = prd.rayDirection.z;
+    o[9] = prd.weight.x; o[10] = prd.weight.y; o[11] = prd.weight.z;
+    o[12] = prd.isSpecular ? 1.0f : 0.0f;
+    o[13] = prd.lightDist;
+    o[14] = prd.shadowRayDir.x; o[15] = prd.shadowRayDir.y; o[16] = prd.shadowRayDir.z;
+    memcpy(o + 17, &prd.seed, 4);
+    o[18] = 0; o[19] = 0;
+  }
+}
+
+/* Camera ray of raytrace.rgen:30,42-51 for pixel (x,y), jitter (jx,jy): out = origin3, dir3. */
+void orc_camera_ray(const GlobalUniforms* uni, uint32_t x, uint32_t y, uint32_t W, uint32_t H, float jx, float jy, float* out6)
+{
+  const float o4[4] = {0, 0, 0, 1};
+  float origin[4];
+  mat4MulVec4(uni->viewInverse, o4, origin);
+  float pcx = (float)x + jx, pcy = (float)y + jy;
+  float inU = pcx / (float)W, inV = pcy / (float)H;
+  float dx = inU * 2.0f - 1.0f, dy = inV * 2.0f - 1.0f;
+  const float d4[4] = {dx, dy, 1, 1};
+  float target[4];
+  mat4MulVec4(uni->projInverse, d4, target);
+  V3 tn = normalize(v3(target[0], target[1], target[2]));
+  const float t4[4] = {tn.x, tn.y, tn.z, 0};
+  float direction[4];
+  mat4MulVec4(uni->viewInverse, t4, direction);
+  out6[0] = origin[0]; out6[1] = origin[1]; out6[2] = origin[2];
+  out6[3] = direction[0]; out6[4] = direction[1]; out6[5] = direction[2];
+}
+
+/* Bilinear sampler spot check: uv = float[2n] -> rgba float[4n] from texture texIndex. */
+void orc_sample_texture(const orc_scene* s, int texIndex, uint32_t n, const float* uv, float* rgba)
+{
+  Counters c;
+  for(uint32_t i = 0; i < n; i++)
+  {
+    V4 r = sampleTex(*s, texIndex, uv[2 * i], uv[2 * i + 1], c);
+    rgba[4 * i] = r.x; rgba[4 * i + 1] = r.y; rgba[4 * i + 2] = r.z; rgba[4 * i + 3] = r.w;
+  }
+}
+
+}  // extern "C"

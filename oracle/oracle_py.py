@@ -1,0 +1,174 @@
+"""ctypes wrapper around oracle/liboracle.so (TEST INFRASTRUCTURE ONLY, see oracle.cpp).
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the
+product package."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+import vkrt_amd  # noqa: E402,F401
+from vkrt_amd import abi  # noqa: E402
+
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle` or __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        P = C.POINTER
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_tea.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_tea.restype = C.c_uint32
+        L.orc_lcg.argtypes = [P(C.c_uint32)]
+        L.orc_lcg.restype = C.c_uint32
+        L.orc_rnd.argtypes = [P(C.c_uint32)]
+        L.orc_rnd.restype = C.c_float
+        L.orc_scene_create.argtypes = [P(abi.SceneDesc)]
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_triangle_count.argtypes = [C.c_void_p]
+        L.orc_triangle_count.restype = C.c_uint32
+        L.orc_build_bvh.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_bvh_info.argtypes = [C.c_void_p, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32), P(C.c_double)]
+        L.orc_get_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_render_rows.argtypes = [C.c_void_p, P(abi.PushConstantRay), P(abi.GlobalUniforms), C.c_uint32, C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_render_rows.restype = C.c_int
+        L.orc_pixel_log.argtypes = [C.c_void_p, P(abi.PushConstantRay), P(abi.GlobalUniforms), C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_pixel_log.restype = C.c_int
+        L.orc_trace_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_eval_math.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_eval_shade.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_camera_ray.argtypes = [P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+        L.orc_sample_texture.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+COUNTER_NAMES = [n for n, _ in abi.Counters._fields_]
+
+
+class OracleScene:
+    def __init__(self, flat, build_bvh=True, max_leaf=4):
+        self._flat = flat
+        desc, self._keep = flat.to_desc()
+        self._h = lib().orc_scene_create(C.byref(desc))
+        if not self._h:
+            raise RuntimeError("orc_scene_create: " + lib().orc_last_error().decode())
+        self.has_bvh = False
+        if build_bvh:
+            self.build_bvh(max_leaf)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    @property
+    def triangle_count(self):
+        return int(lib().orc_triangle_count(self._h))
+
+    def build_bvh(self, max_leaf=4):
+        lib().orc_build_bvh(self._h, max_leaf)
+        self.has_bvh = True
+
+    def bvh_info(self):
+        n, l, d, s = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()
+        lib().orc_bvh_info(self._h, C.byref(n), C.byref(l), C.byref(d), C.byref(s))
+        return {"nodes": n.value, "leaves": l.value, "max_depth": d.value, "sah_cost": s.value}
+
+    def triangles(self):
+        n = self.triangle_count
+        v = np.zeros((n, 9), np.float32)
+        ids = np.zeros((n, 3), np.uint32)
+        lib().orc_get_triangles(self._h, v.ctypes.data, ids.ctypes.data)
+        return v, ids
+
+    def render(self, pc, cam, width, height, seed=0, flags=0, rows=None, image=None, use_bvh=True, threads=0):
+        """Returns (image[nrows,W,4] float32, counters dict).  image is in/out when pc.frame > 0."""
+        rows = np.arange(height, dtype=np.uint32) if rows is None else np.ascontiguousarray(rows, np.uint32)
+        if image is None:
+            image = np.zeros((rows.shape[0], width, 4), np.float32)
+        assert image.shape == (rows.shape[0], width, 4) and image.dtype == np.float32 and image.flags.c_contiguous
+        cnt = np.zeros(8, np.uint64)
+        rc = lib().orc_render_rows(self._h, C.byref(pc), C.byref(cam), seed, flags, width, height, rows.ctypes.data,
+                                   rows.shape[0], image.ctypes.data, 1 if use_bvh else 0, threads, cnt.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_render_rows: " + lib().orc_last_error().decode())
+        return image, dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
+
+    def pixel_log(self, pc, cam, width, height, x, y, seed=0, flags=0, use_bvh=True):
+        px = np.zeros(4, np.float32)
+        log = np.zeros(16 * 64 * max(1, pc.samples), np.float32)
+        n = lib().orc_pixel_log(self._h, C.byref(pc), C.byref(cam), seed, flags, width, height, x, y, 1 if use_bvh else 0,
+                                px.ctypes.data, log.ctypes.data, log.shape[0])
+        return px, log[: min(n, log.shape[0])].reshape(-1, 8)
+
+    def trace_rays(self, origins, directions, tmin=0.001, tmax=10000.0, any_hit=False, use_bvh=True):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t, u, v = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        gid = np.zeros(n, np.int32)
+        cnt = np.zeros(8, np.uint64)
+        lib().orc_trace_rays(self._h, n, o.ctypes.data, d.ctypes.data, tmin, tmax, 1 if any_hit else 0, 1 if use_bvh else 0,
+                             t.ctypes.data, u.ctypes.data, v.ctypes.data, gid.ctypes.data, cnt.ctypes.data)
+        return t, u, v, gid, {"nodes_visited": int(cnt[6]), "tris_tested": int(cnt[7])}
+
+    def sample_texture(self, tex_index, uv):
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((uv.shape[0], 4), np.float32)
+        lib().orc_sample_texture(self._h, tex_index, uv.shape[0], uv.ctypes.data, out.ctypes.data)
+        return out
+
+
+def tea(a, b):
+    return int(lib().orc_tea(a & 0xFFFFFFFF, b & 0xFFFFFFFF))
+
+
+def lcg_sequence(state, n):
+    s = C.c_uint32(state)
+    out = []
+    for _ in range(n):
+        bits = int(lib().orc_lcg(C.byref(s)))
+        out.append((int(s.value), bits, bits / 16777216.0))
+    return out
+
+
+def eval_math(op, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(a if b is None else b, np.float32)
+    out = np.zeros_like(a)
+    lib().orc_eval_math(op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return out
+
+
+def eval_shade(inputs):
+    inputs = np.ascontiguousarray(inputs, np.float32).reshape(-1, 40)
+    out = np.zeros((inputs.shape[0], 20), np.float32)
+    lib().orc_eval_shade(inputs.shape[0], inputs.ctypes.data, out.ctypes.data)
+    return out
+
+
+def camera_ray(cam, x, y, W, H, jx=0.5, jy=0.5):
+    out = np.zeros(6, np.float32)
+    lib().orc_camera_ray(C.byref(cam), x, y, W, H, jx, jy, out.ctypes.data)
+    return out[:3], out[3:]
+
+
+def algorithmic_bytes(counters, frame_gt0=False):
+    """SURVEY.md 8(d) contract figure: 64 B/visited node, 48 B/triangle test, 220 B/closest hit,
+    32 B/diffuse hit (light), 16 B/texture tap, 16 B/pixel written (+16 read when frame>0)."""
+    c = counters
+    return (64 * c["nodes_visited"] + 48 * c["tris_tested"] + 220 * c["hits"] + 32 * c["diffuse_hits"]
+            + 16 * c["tex_taps"] + (32 if frame_gt0 else 16) * c["pixels"])

@@ -1,0 +1,207 @@
+"""ctypes mirror of include/vkrt.h and include/vkrt_host_device.h.
+
+Harness-side only: the product is the C-ABI library (csrc/ -> libvkrt.so); this module
+declares its structs and prototypes so tests and bench.py can call it.  Layout sizes
+are asserted against the reference contract (reference: shaders/host_device.h:68-137,
+SURVEY.md Appendix B).
+"""
+import ctypes as C
+
+c_f = C.c_float
+c_i = C.c_int32
+c_u = C.c_uint32
+c_u64 = C.c_uint64
+
+
+class Mat4(C.Structure):
+    _fields_ = [("m", c_f * 16)]
+
+
+class GlobalUniforms(C.Structure):
+    _fields_ = [("viewProj", Mat4), ("viewInverse", Mat4), ("projInverse", Mat4)]
+
+
+class PushConstantRay(C.Structure):
+    _fields_ = [
+        ("clearColor", c_f * 4),
+        ("frame", c_i),
+        ("lightsCount", c_i),
+        ("samples", c_i),
+        ("depth", c_i),
+        ("useShadows", c_i),
+        ("useAO", c_i),
+        ("useGI", c_i),
+    ]
+
+
+class PrimMeshInfo(C.Structure):
+    _fields_ = [("indexOffset", c_u), ("vertexOffset", c_u), ("materialIndex", c_i)]
+
+
+class GltfPBRMaterial(C.Structure):
+    _fields_ = [
+        ("pbrBaseColorFactor", c_f * 4),
+        ("pbrBaseColorTexture", c_i),
+        ("metallicFactor", c_f),
+        ("roughnessFactor", c_f),
+        ("metallicRoughnessTexture", c_i),
+        ("normalTexture", c_i),
+        ("emissiveFactor", c_f * 3),
+        ("emissiveTexture", c_i),
+    ]
+
+
+class GltfLight(C.Structure):
+    _fields_ = [("position", c_f * 3), ("color", c_f * 3), ("intensity", c_f), ("type", c_i)]
+
+
+class PrimMesh(C.Structure):
+    _fields_ = [
+        ("firstIndex", c_u),
+        ("indexCount", c_u),
+        ("vertexOffset", c_u),
+        ("vertexCount", c_u),
+        ("materialIndex", c_i),
+    ]
+
+
+class Node(C.Structure):
+    _fields_ = [("worldMatrix", c_f * 16), ("primMesh", c_i)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", c_u), ("height", c_u), ("rgba8", C.c_void_p), ("is_srgb", c_i)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", c_u),
+        ("vertex_count", c_u),
+        ("positions", C.c_void_p),
+        ("normals", C.c_void_p),
+        ("tangents", C.c_void_p),
+        ("texcoords0", C.c_void_p),
+        ("indices", C.c_void_p),
+        ("index_count", c_u),
+        ("prim_mesh_count", c_u),
+        ("prim_meshes", C.c_void_p),
+        ("materials", C.c_void_p),
+        ("material_count", c_u),
+        ("light_count", c_u),
+        ("lights", C.c_void_p),
+        ("nodes", C.c_void_p),
+        ("node_count", c_u),
+        ("texture_count", c_u),
+        ("textures", C.c_void_p),
+    ]
+
+
+class Shard(C.Structure):
+    _fields_ = [
+        ("full_width", c_u),
+        ("full_height", c_u),
+        ("strip_rows", c_u),
+        ("shard_count", c_u),
+        ("shard_index", c_u),
+    ]
+
+
+class TraceOpts(C.Structure):
+    _fields_ = [("seed", c_u), ("flags", c_u)]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("rays_closest", c_u64),
+        ("rays_shadow", c_u64),
+        ("hits", c_u64),
+        ("diffuse_hits", c_u64),
+        ("tex_taps", c_u64),
+        ("pixels", c_u64),
+        ("nodes_visited", c_u64),
+        ("tris_tested", c_u64),
+    ]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class AccelInfo(C.Structure):
+    _fields_ = [
+        ("triangle_count", c_u),
+        ("node_count", c_u),
+        ("max_depth", c_u),
+        ("build_flags", c_u),
+        ("sah_cost", c_f),
+        ("build_ms", c_f),
+        ("node_bytes", c_u64),
+        ("triangle_bytes", c_u64),
+    ]
+
+
+# layout contract
+assert C.sizeof(GlobalUniforms) == 192
+assert C.sizeof(PushConstantRay) == 44
+assert C.sizeof(PrimMeshInfo) == 12
+assert C.sizeof(GltfPBRMaterial) == 52
+assert C.sizeof(GltfLight) == 32
+assert C.sizeof(PrimMesh) == 20
+assert C.sizeof(Node) == 68
+
+VKRT_BUILD_LBVH_GPU = 0x1
+VKRT_BUILD_SAH_HOST = 0x2
+VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1
+VKRT_TRACE_COUNT_TRAVERSAL = 0x2
+
+# every symbol include/vkrt.h declares (tests check the built library exports them all)
+VKRT_SYMBOLS = [
+    "vkrt_abi_version",
+    "vkrt_last_error",
+    "vkrt_device_count",
+    "vkrt_scene_create",
+    "vkrt_scene_destroy",
+    "vkrt_accel_build",
+    "vkrt_accel_get_info",
+    "vkrt_shard_rows",
+    "vkrt_pathtrace",
+    "vkrt_counters_reset",
+    "vkrt_counters_read",
+    "vkrt_last_trace_ms",
+    "vkrt_debug_trace_rays",
+    "vkrt_debug_eval_math",
+]
+
+
+def declare_vkrt(lib):
+    """Attach argtypes/restype for the C ABI to a loaded libvkrt.so."""
+    P = C.POINTER
+    lib.vkrt_abi_version.restype = C.c_int
+    lib.vkrt_last_error.restype = C.c_char_p
+    lib.vkrt_device_count.restype = C.c_int
+    lib.vkrt_scene_create.argtypes = [P(SceneDesc), C.c_int, P(C.c_void_p)]
+    lib.vkrt_scene_create.restype = C.c_int
+    lib.vkrt_scene_destroy.argtypes = [C.c_void_p]
+    lib.vkrt_scene_destroy.restype = None
+    lib.vkrt_accel_build.argtypes = [C.c_void_p, c_u, C.c_void_p]
+    lib.vkrt_accel_build.restype = C.c_int
+    lib.vkrt_accel_get_info.argtypes = [C.c_void_p, P(AccelInfo)]
+    lib.vkrt_accel_get_info.restype = C.c_int
+    lib.vkrt_shard_rows.argtypes = [P(Shard)]
+    lib.vkrt_shard_rows.restype = c_u
+    lib.vkrt_pathtrace.argtypes = [
+        C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), C.c_void_p, C.c_void_p,
+    ]
+    lib.vkrt_pathtrace.restype = C.c_int
+    lib.vkrt_counters_reset.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vkrt_counters_reset.restype = C.c_int
+    lib.vkrt_counters_read.argtypes = [C.c_void_p, P(Counters)]
+    lib.vkrt_counters_read.restype = C.c_int
+    lib.vkrt_last_trace_ms.argtypes = [C.c_void_p, P(c_f)]
+    lib.vkrt_last_trace_ms.restype = C.c_int
+    lib.vkrt_debug_trace_rays.argtypes = [
+        C.c_void_p, c_u, C.c_void_p, C.c_void_p, c_f, c_f, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    ]
+    lib.vkrt_debug_trace_rays.restype = C.c_int
+    lib.vkrt_debug_eval_math.argtypes = [C.c_int, C.c_int, c_u, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vkrt_debug_eval_math.restype = C.c_int
+    return lib
