@@ -1,0 +1,297 @@
+// bvh_host.cpp -- host-side binned-SAH BVH2 builder (VKRT_BUILD_SAH_HOST).
+//
+// Replaces the driver's PREFER_FAST_TRACE acceleration-structure build that the reference requests
+// through nvvk::RaytracingBuilderKHR (hello_vulkan.cpp:1001-1011 buildBlas, :1031-1047 buildTlas).
+// All TLAS instances are flattened to world space first (bvh_host.h: flatten_instances), so one
+// BVH covers the whole scene.  Output is the 64-byte node / 48-byte triangle layout of
+// device_scene.h, nodes in depth-first order (a node's first child is usually the next line).
+#include "bvh_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vkrt {
+
+namespace {
+
+struct Box
+{
+  float lo[3], hi[3];
+  void reset()
+  {
+    for(int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+  }
+  void grow(const Box& b)
+  {
+    for(int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+  }
+  void growPt(const float* p)
+  {
+    for(int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+  }
+  float area() const
+  {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if(!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f))
+      return 0.f;
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+constexpr int kBins = 32;
+constexpr float kTraversalCost = 1.0f;
+constexpr float kIntersectCost = 1.0f;
+constexpr uint32_t kMaxDepth = 60;
+
+struct Ctx
+{
+  const std::vector<FlatTri>& tris;
+  std::vector<Box> tb;
+  std::vector<float> cen;  // 3 per tri
+  std::vector<uint32_t> order;
+  BuiltBvh& out;
+  uint32_t maxLeaf;
+  double sah = 0;
+
+  Ctx(const std::vector<FlatTri>& t, BuiltBvh& o, uint32_t ml) : tris(t), out(o), maxLeaf(ml) {}
+
+  int32_t emitLeaf(uint32_t first, uint32_t count)
+  {
+    const uint32_t slot0 = (uint32_t)out.triOrder.size();
+    for(uint32_t k = 0; k < count; k++)
+      out.triOrder.push_back(order[first + k]);
+    const uint32_t code = (slot0 << 3) | (count - 1u);
+    return (int32_t)~code;
+  }
+
+  // returns child ref; cost = SAH cost of the subtree relative to its own box
+  int32_t build(uint32_t first, uint32_t count, const Box& box, uint32_t depth, double& cost)
+  {
+    out.maxDepth = std::max(out.maxDepth, depth);
+    if(count <= 1u || (count <= maxLeaf && depth >= kMaxDepth))
+    {
+      cost = kIntersectCost * count;
+      return emitLeaf(first, count);
+    }
+    // centroid bounds
+    Box cb;
+    cb.reset();
+    for(uint32_t k = 0; k < count; k++)
+      cb.growPt(&cen[3 * order[first + k]]);
+    const float parentArea = box.area();
+    float bestCost = INFINITY;
+    int bestAxis = -1, bestBin = -1;
+    if(depth < kMaxDepth)
+    {
+      for(int axis = 0; axis < 3; axis++)
+      {
+        const float ext = cb.hi[axis] - cb.lo[axis];
+        if(!(ext > 0.f))
+          continue;
+        Box bins[kBins];
+        uint32_t cnt[kBins];
+        for(int b = 0; b < kBins; b++) { bins[b].reset(); cnt[b] = 0; }
+        const float scale = (float)kBins / ext;
+        for(uint32_t k = 0; k < count; k++)
+        {
+          const uint32_t t = order[first + k];
+          int b = (int)((cen[3 * t + axis] - cb.lo[axis]) * scale);
+          b = std::min(std::max(b, 0), kBins - 1);
+          bins[b].grow(tb[t]);
+          cnt[b]++;
+        }
+        float rightArea[kBins];
+        uint32_t rightCnt[kBins];
+        Box acc;
+        acc.reset();
+        uint32_t c = 0;
+        for(int b = kBins - 1; b > 0; b--)
+        {
+          acc.grow(bins[b]);
+          c += cnt[b];
+          rightArea[b] = acc.area();
+          rightCnt[b] = c;
+        }
+        acc.reset();
+        c = 0;
+        for(int b = 1; b < kBins; b++)
+        {
+          acc.grow(bins[b - 1]);
+          c += cnt[b - 1];
+          if(c == 0 || rightCnt[b] == 0)
+            continue;
+          const float cst = acc.area() * (float)c + rightArea[b] * (float)rightCnt[b];
+          if(cst < bestCost) { bestCost = cst; bestAxis = axis; bestBin = b; }
+        }
+      }
+    }
+    const float leafCost = kIntersectCost * (float)count;
+    const float splitCost = (bestAxis >= 0 && parentArea > 0.f) ? kTraversalCost + kIntersectCost * bestCost / parentArea : INFINITY;
+    if(count <= maxLeaf && !(splitCost < leafCost))
+    {
+      cost = leafCost;
+      return emitLeaf(first, count);
+    }
+    uint32_t mid;
+    uint32_t* ord = &order[first];
+    if(bestAxis >= 0)
+    {
+      const float ext = cb.hi[bestAxis] - cb.lo[bestAxis];
+      const float scale = (float)kBins / ext;
+      const float lo = cb.lo[bestAxis];
+      const int axis = bestAxis, bin = bestBin;
+      uint32_t* m = std::partition(ord, ord + count, [&](uint32_t t) {
+        int b = (int)((cen[3 * t + axis] - lo) * scale);
+        b = std::min(std::max(b, 0), kBins - 1);
+        return b < bin;
+      });
+      mid = (uint32_t)(m - ord);
+    }
+    else
+      mid = 0;
+    if(mid == 0 || mid == count)
+    {  // degenerate (coincident centroids / depth cap): object median on the widest axis
+      int axis = 0;
+      for(int k = 1; k < 3; k++)
+        if(cb.hi[k] - cb.lo[k] > cb.hi[axis] - cb.lo[axis]) axis = k;
+      mid = count / 2;
+      std::nth_element(ord, ord + mid, ord + count, [&](uint32_t a, uint32_t b) {
+        const float ca = cen[3 * a + axis], cb2 = cen[3 * b + axis];
+        return ca < cb2 || (ca == cb2 && a < b);
+      });
+    }
+    Box b0, b1;
+    b0.reset(); b1.reset();
+    for(uint32_t k = 0; k < mid; k++) b0.grow(tb[ord[k]]);
+    for(uint32_t k = mid; k < count; k++) b1.grow(tb[ord[k]]);
+
+    const uint32_t me = (uint32_t)(out.nodes.size() / 16);
+    out.nodes.resize(out.nodes.size() + 16);
+    double c0 = 0, c1 = 0;
+    const int32_t ch0 = build(first, mid, b0, depth + 1, c0);
+    const int32_t ch1 = build(first + mid, count - mid, b1, depth + 1, c1);
+    float* n = &out.nodes[(size_t)me * 16];
+    n[0] = b0.lo[0]; n[1] = b0.lo[1]; n[2] = b0.lo[2]; n[3] = b0.hi[0];
+    n[4] = b0.hi[1]; n[5] = b0.hi[2]; n[6] = b1.lo[0]; n[7] = b1.lo[1];
+    n[8] = b1.lo[2]; n[9] = b1.hi[0]; n[10] = b1.hi[1]; n[11] = b1.hi[2];
+    memcpy(&n[12], &ch0, 4);
+    memcpy(&n[13], &ch1, 4);
+    n[14] = 0.f; n[15] = 0.f;
+    const double pa = parentArea > 0.f ? parentArea : 1.0;
+    cost = kTraversalCost + (b0.area() * c0 + b1.area() * c1) / pa;
+    return (int32_t)me;
+  }
+};
+
+}  // namespace
+
+void invert3x3_rows(const float o2w[12], float w2o[9])
+{
+  // cofactor inverse of the upper-left 3x3 in double, fixed operation order
+  const double a = o2w[0], b = o2w[1], c = o2w[2];
+  const double d = o2w[4], e = o2w[5], f = o2w[6];
+  const double g = o2w[8], h = o2w[9], i = o2w[10];
+  const double A = e * i - f * h;
+  const double B = -(d * i - f * g);
+  const double C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  const double inv = 1.0 / det;
+  w2o[0] = (float)(A * inv);
+  w2o[1] = (float)(-(b * i - c * h) * inv);
+  w2o[2] = (float)((b * f - c * e) * inv);
+  w2o[3] = (float)(B * inv);
+  w2o[4] = (float)((a * i - c * g) * inv);
+  w2o[5] = (float)(-(a * f - c * d) * inv);
+  w2o[6] = (float)(C * inv);
+  w2o[7] = (float)(-(a * h - b * g) * inv);
+  w2o[8] = (float)((a * e - b * d) * inv);
+}
+
+static inline void xformPoint(const float m[12], const float* p, float* r)
+{
+  r[0] = ((m[0] * p[0] + m[1] * p[1]) + m[2] * p[2]) + m[3];
+  r[1] = ((m[4] * p[0] + m[5] * p[1]) + m[6] * p[2]) + m[7];
+  r[2] = ((m[8] * p[0] + m[9] * p[1]) + m[10] * p[2]) + m[11];
+}
+
+void flatten_instances(const float* positions, const uint32_t* indices, const vkrt_prim_mesh* pm, const vkrt_node* nodes,
+                       uint32_t nodeCount, std::vector<FlatTri>& out)
+{
+  out.clear();
+  uint32_t gid = 0;
+  for(uint32_t n = 0; n < nodeCount; n++)
+  {
+    float m[12];
+    for(int r = 0; r < 3; r++)
+      for(int c = 0; c < 4; c++)
+        m[r * 4 + c] = nodes[n].worldMatrix[c * 4 + r];
+    const vkrt_prim_mesh& p = pm[nodes[n].primMesh];
+    for(uint32_t t = 0; t < p.indexCount / 3; t++)
+    {
+      const uint32_t i0 = indices[p.firstIndex + 3 * t + 0] + p.vertexOffset;
+      const uint32_t i1 = indices[p.firstIndex + 3 * t + 1] + p.vertexOffset;
+      const uint32_t i2 = indices[p.firstIndex + 3 * t + 2] + p.vertexOffset;
+      float a[3], b[3], c[3];
+      xformPoint(m, positions + 3 * (size_t)i0, a);
+      xformPoint(m, positions + 3 * (size_t)i1, b);
+      xformPoint(m, positions + 3 * (size_t)i2, c);
+      FlatTri ft;
+      for(int k = 0; k < 3; k++) { ft.v0[k] = a[k]; ft.e1[k] = b[k] - a[k]; ft.e2[k] = c[k] - a[k]; }
+      ft.gid = gid++; ft.inst = n; ft.prim = t;
+      out.push_back(ft);
+    }
+  }
+}
+
+void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh& out)
+{
+  out.nodes.clear(); out.triOrder.clear(); out.maxDepth = 0; out.sahCost = 0; out.rootRef = (int32_t)0x80000000;
+  const uint32_t n = (uint32_t)tris.size();
+  if(n == 0)
+    return;
+  Ctx cx(tris, out, std::min<uint32_t>(std::max<uint32_t>(maxLeaf, 1u), 8u));
+  cx.tb.resize(n); cx.cen.resize(3 * (size_t)n); cx.order.resize(n);
+  out.triOrder.reserve(n);
+  out.nodes.reserve((size_t)n * 16);
+  Box all;
+  all.reset();
+  for(uint32_t i = 0; i < n; i++)
+  {
+    const FlatTri& t = tris[i];
+    Box b;
+    for(int k = 0; k < 3; k++)
+    {
+      const float p0 = t.v0[k], p1 = t.v0[k] + t.e1[k], p2 = t.v0[k] + t.e2[k];
+      // boxes must contain what the ray/triangle test sees: the test works from (v0,e1,e2), and
+      // v0+e1 may round away from the original vertex, so bound both forms.
+      b.lo[k] = std::min(p0, std::min(p1, p2));
+      b.hi[k] = std::max(p0, std::max(p1, p2));
+      cx.cen[3 * (size_t)i + k] = 0.5f * (b.lo[k] + b.hi[k]);
+    }
+    cx.tb[i] = b;
+    cx.order[i] = i;
+    all.grow(b);
+  }
+  double cost = 0;
+  out.rootRef = cx.build(0, n, all, 0, cost);
+  out.sahCost = (float)cost;
+}
+
+void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out)
+{
+  out.resize(order.size() * 12);
+  for(size_t s = 0; s < order.size(); s++)
+  {
+    const FlatTri& t = tris[order[s]];
+    float* o = &out[s * 12];
+    o[0] = t.v0[0]; o[1] = t.v0[1]; o[2] = t.v0[2]; o[3] = t.e1[0];
+    o[4] = t.e1[1]; o[5] = t.e1[2]; o[6] = t.e2[0]; o[7] = t.e2[1];
+    o[8] = t.e2[2];
+    memcpy(&o[9], &t.gid, 4);
+    memcpy(&o[10], &t.inst, 4);
+    memcpy(&o[11], &t.prim, 4);
+  }
+}
+
+}  // namespace vkrt

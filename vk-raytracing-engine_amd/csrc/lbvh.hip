@@ -1,0 +1,469 @@
+// lbvh.hip -- GPU LBVH builder (VKRT_BUILD_LBVH_GPU): the device-side replacement for the
+// driver's acceleration-structure build that the reference triggers through
+// nvvk::RaytracingBuilderKHR::buildBlas/buildTlas (hello_vulkan.cpp:1001-1047).
+//
+// Pipeline (all on the caller's stream, one-off per scene):
+//   k_flatten   instances x primitives -> world-space (v0,e1,e2) records + boxes + scene bounds
+//   k_morton    63-bit Morton code of each box centre (21 bits per axis)
+//   rocprim     radix sort of (code, gid) pairs (stable: equal codes stay in gid order)
+//   k_hierarchy Karras 2012 radix tree over the sorted codes (ties resolved by position)
+//   k_fit       bottom-up boxes with per-node arrival counters
+//   k_emit      64-byte two-child nodes; subtrees of <= LEAF triangles collapse into one leaf
+//   k_pack      48-byte triangle records in sorted (leaf) order
+// Triangle arithmetic is the same sequence as the host flatten (bvh_host.cpp) so both builders
+// hand bit-identical triangles to the traversal kernel.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "device_math.h"
+#include "lbvh.h"
+
+namespace vkrt {
+
+namespace {
+
+constexpr unsigned kLeaf = 4;
+
+struct FlatArgs
+{
+  const float* positions;
+  const uint32_t* indices;
+  const DevInstance* instances;
+  const uint32_t* instFirstGid;  // [instCount+1]
+  const uint32_t* instFirstIndex;
+  const uint32_t* instVertexOffset;
+  uint32_t instCount;
+  uint32_t triCount;
+};
+
+VKRT_DEV unsigned encodeOrdered(float f)
+{
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float decodeOrdered(unsigned u)
+{
+  const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(b);
+#else
+  memcpy(&f, &b, 4);
+#endif
+  return f;
+}
+
+__global__ void k_flatten(FlatArgs A, float4* triU, float* triBox /*6 per tri*/, unsigned* sceneBounds /*lo3 hi3 ordered*/)
+{
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if(gid < A.triCount)
+  {
+    // instance lookup: largest n with instFirstGid[n] <= gid
+    unsigned a = 0, b = A.instCount;
+    while(b - a > 1u)
+    {
+      const unsigned m = (a + b) >> 1;
+      if(A.instFirstGid[m] <= gid) a = m; else b = m;
+    }
+    const unsigned inst = a, prim = gid - A.instFirstGid[a];
+    const DevInstance in = A.instances[inst];
+    const uint32_t base = A.instFirstIndex[inst] + 3u * prim, vo = A.instVertexOffset[inst];
+    const uint32_t i0 = A.indices[base] + vo, i1 = A.indices[base + 1] + vo, i2 = A.indices[base + 2] + vo;
+    f3 p[3];
+    const uint32_t ii[3] = {i0, i1, i2};
+#pragma unroll
+    for(int k = 0; k < 3; k++)
+    {
+      const f3 q = mk3(A.positions[3 * ii[k]], A.positions[3 * ii[k] + 1], A.positions[3 * ii[k] + 2]);
+      p[k].x = ((in.o2w[0] * q.x + in.o2w[1] * q.y) + in.o2w[2] * q.z) + in.o2w[3];
+      p[k].y = ((in.o2w[4] * q.x + in.o2w[5] * q.y) + in.o2w[6] * q.z) + in.o2w[7];
+      p[k].z = ((in.o2w[8] * q.x + in.o2w[9] * q.y) + in.o2w[10] * q.z) + in.o2w[11];
+    }
+    const f3 v0 = p[0], e1 = p[1] - p[0], e2 = p[2] - p[0];
+    triU[3 * (size_t)gid + 0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    triU[3 * (size_t)gid + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    triU[3 * (size_t)gid + 2] = make_float4(e2.z, __int_as_float((int)gid), __int_as_float((int)inst), __int_as_float((int)prim));
+    const float vv[3] = {v0.x, v0.y, v0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+#pragma unroll
+    for(int k = 0; k < 3; k++)
+    {
+      const float p0 = vv[k], p1 = vv[k] + a1[k], p2 = vv[k] + a2[k];
+      lo[k] = fminf(p0, fminf(p1, p2));
+      hi[k] = fmaxf(p0, fmaxf(p1, p2));
+      triBox[6 * (size_t)gid + k] = lo[k];
+      triBox[6 * (size_t)gid + 3 + k] = hi[k];
+    }
+  }
+  // wave reduce then one atomic per wave per component
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    float l = lo[k], h = hi[k];
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+    {
+      l = fminf(l, __shfl_xor(l, off));
+      h = fmaxf(h, __shfl_xor(h, off));
+    }
+    if((threadIdx.x & 63u) == 0u)
+    {
+      if(l <= h)
+      {
+        atomicMin(&sceneBounds[k], encodeOrdered(l));
+        atomicMax(&sceneBounds[3 + k], encodeOrdered(h));
+      }
+    }
+  }
+}
+
+VKRT_DEV unsigned long long expand21(unsigned v)
+{
+  unsigned long long x = v & 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ void k_morton(unsigned n, const float* triBox, const unsigned* sceneBounds, unsigned long long* keys, unsigned* vals)
+{
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  unsigned q[3];
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    const float lo = decodeOrdered(sceneBounds[k]), hi = decodeOrdered(sceneBounds[3 + k]);
+    const float c = 0.5f * (triBox[6 * (size_t)i + k] + triBox[6 * (size_t)i + 3 + k]);
+    const float ext = hi - lo;
+    float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
+    t = fminf(fmaxf(t * 2097152.0f, 0.0f), 2097151.0f);
+    q[k] = (unsigned)t;
+  }
+  keys[i] = expand21(q[0]) | (expand21(q[1]) << 1) | (expand21(q[2]) << 2);
+  vals[i] = i;
+}
+
+// common-prefix length of sorted keys i and j (position breaks ties); -1 outside the array
+VKRT_DEV int delta(const unsigned long long* keys, int n, int i, int j)
+{
+  if(j < 0 || j >= n)
+    return -1;
+  const unsigned long long a = keys[i], b = keys[j];
+  if(a == b)
+    return 64 + __clz((unsigned)i ^ (unsigned)j);
+  return __clzll((long long)(a ^ b));
+}
+
+// Karras 2012, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", Alg. in section 4.
+// child index encoding: >= 0 internal node, < 0 : ~leafPosition
+__global__ void k_hierarchy(int n, const unsigned long long* keys, int2* children, int2* range, int* parentInternal, int* parentLeaf)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n - 1)
+    return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while(delta(keys, n, i, i + lmax * d) > dmin)
+    lmax *= 2;
+  int l = 0;
+  for(int t = lmax / 2; t >= 1; t /= 2)
+    if(delta(keys, n, i, i + (l + t) * d) > dmin)
+      l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  int t = l;
+  do
+  {
+    t = (t + 1) >> 1;
+    if(delta(keys, n, i, i + (s + t) * d) > dnode)
+      s += t;
+  } while(t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  int2 ch;
+  if(lo == gamma) { ch.x = ~gamma; parentLeaf[gamma] = i; }
+  else { ch.x = gamma; parentInternal[gamma] = i; }
+  if(hi == gamma + 1) { ch.y = ~(gamma + 1); parentLeaf[gamma + 1] = i; }
+  else { ch.y = gamma + 1; parentInternal[gamma + 1] = i; }
+  children[i] = ch;
+  range[i] = make_int2(lo, hi);
+  if(i == 0)
+    parentInternal[0] = -1;
+}
+
+// bottom-up boxes: the second thread to arrive at a node owns it.  Cross-CU visibility of the
+// sibling's box follows the agent-scope release/acquire rule (guide section 6, Guideline 16):
+// __threadfence() before the arrival atomic (release) and after it (acquire).
+__global__ void k_fit(int n, const unsigned* order, const float* triBox, const int2* children, const int* parentInternal,
+                      const int* parentLeaf, float* nodeBox, unsigned* arrive)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n)
+    return;
+  int node = parentLeaf[k];
+  while(node >= 0)
+  {
+    __threadfence();
+    const unsigned prev = atomicAdd(&arrive[node], 1u);
+    if(prev == 0u)
+      return;
+    __threadfence();
+    const int2 ch = children[node];
+    float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const int cc[2] = {ch.x, ch.y};
+#pragma unroll
+    for(int c = 0; c < 2; c++)
+    {
+      const float* src = cc[c] < 0 ? &triBox[6 * (size_t)order[~cc[c]]] : &nodeBox[6 * (size_t)cc[c]];
+      // bypass this CU's L1 (boxes written by other CUs): agent-scope relaxed atomic loads
+#pragma unroll
+      for(int q = 0; q < 3; q++)
+      {
+        b[q] = fminf(b[q], __hip_atomic_load(&src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b[3 + q] = fmaxf(b[3 + q], __hip_atomic_load(&src[3 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+    }
+#pragma unroll
+    for(int q = 0; q < 6; q++)
+      __hip_atomic_store(&nodeBox[6 * (size_t)node + q], b[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    node = parentInternal[node];
+  }
+}
+
+VKRT_DEV float boxArea(const float* b)
+{
+  const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+  return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+__global__ void k_emit(int n, const unsigned* order, const float* triBox, const int2* children, const int2* range, const float* nodeBox,
+                       float4* outNodes, float* sahAccum)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n - 1)
+    return;
+  const int2 rg = range[i];
+  const unsigned cnt = (unsigned)(rg.y - rg.x + 1);
+  if(cnt <= kLeaf && i != 0)
+    return;  // lives inside a collapsed leaf
+  const int2 ch = children[i];
+  const int cc[2] = {ch.x, ch.y};
+  float bx[2][6];
+  int ref[2];
+  float cost = 1.0f * boxArea(&nodeBox[6 * (size_t)i]);
+#pragma unroll
+  for(int c = 0; c < 2; c++)
+  {
+    const float* src;
+    if(cc[c] < 0)
+    {
+      const unsigned pos = (unsigned)~cc[c];
+      src = &triBox[6 * (size_t)order[pos]];
+      ref[c] = (int)~((pos << 3) | 0u);
+      cost += boxArea(src) * 1.0f;
+    }
+    else
+    {
+      src = &nodeBox[6 * (size_t)cc[c]];
+      const int2 cr = range[cc[c]];
+      const unsigned ccnt = (unsigned)(cr.y - cr.x + 1);
+      if(ccnt <= kLeaf)
+      {
+        ref[c] = (int)~(((unsigned)cr.x << 3) | (ccnt - 1u));
+        cost += boxArea(src) * (float)ccnt;
+      }
+      else
+        ref[c] = cc[c];
+    }
+#pragma unroll
+    for(int q = 0; q < 6; q++) bx[c][q] = src[q];
+  }
+  outNodes[4 * (size_t)i + 0] = make_float4(bx[0][0], bx[0][1], bx[0][2], bx[0][3]);
+  outNodes[4 * (size_t)i + 1] = make_float4(bx[0][4], bx[0][5], bx[1][0], bx[1][1]);
+  outNodes[4 * (size_t)i + 2] = make_float4(bx[1][2], bx[1][3], bx[1][4], bx[1][5]);
+  outNodes[4 * (size_t)i + 3] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), 0.0f, 0.0f);
+  atomicAdd(sahAccum, cost);
+}
+
+__global__ void k_pack(unsigned n, const unsigned* order, const float4* triU, float4* outTris)
+{
+  const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+  if(s >= n)
+    return;
+  const unsigned g = order[s];
+  outTris[3 * (size_t)s + 0] = triU[3 * (size_t)g + 0];
+  outTris[3 * (size_t)s + 1] = triU[3 * (size_t)g + 1];
+  outTris[3 * (size_t)s + 2] = triU[3 * (size_t)g + 2];
+}
+
+// depth of the emitted tree = max over leaves of the number of emitted ancestors
+__global__ void k_depth(int n, const int2* range, const int* parentInternal, const int* parentLeaf, unsigned* maxDepth)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= n)
+    return;
+  unsigned d = 0;
+  int node = parentLeaf[k];
+  while(node >= 0)
+  {
+    const int2 rg = range[node];
+    if((unsigned)(rg.y - rg.x + 1) > kLeaf || node == 0)
+      d++;
+    node = parentInternal[node];
+  }
+  atomicMax(maxDepth, d);
+}
+
+struct Temp
+{
+  std::vector<void*> ptrs;
+  ~Temp()
+  {
+    for(void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  hipError_t alloc(T** p, size_t count)
+  {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16));
+    if(e == hipSuccess) ptrs.push_back(q);
+    *p = (T*)q;
+    return e;
+  }
+};
+
+}  // namespace
+
+#define LB_TRY(expr)                                         \
+  do                                                         \
+  {                                                          \
+    hipError_t e_ = (expr);                                  \
+    if(e_ != hipSuccess)                                     \
+    {                                                        \
+      out.error = std::string(#expr) + ": " + hipGetErrorString(e_); \
+      if(out.nodes) (void)hipFree(out.nodes);                \
+      if(out.tris) (void)hipFree(out.tris);                  \
+      out.nodes = out.tris = nullptr;                        \
+      return e_ == hipErrorOutOfMemory ? VKRT_ERR_OUT_OF_MEMORY : VKRT_ERR_HIP; \
+    }                                                        \
+  } while(0)
+
+int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
+                      hipStream_t stream, LbvhResult& out)
+{
+  out = LbvhResult{};
+  std::vector<uint32_t> firstGid(instCount + 1, 0), firstIndex(instCount, 0), vertexOffset(instCount, 0);
+  for(uint32_t n = 0; n < instCount; n++)
+  {
+    const vkrt_prim_mesh& p = pm[nodes[n].primMesh];
+    firstGid[n + 1] = firstGid[n] + p.indexCount / 3;
+    firstIndex[n] = p.firstIndex;
+    vertexOffset[n] = p.vertexOffset;
+  }
+  const uint32_t T = firstGid[instCount];
+  out.triCount = T;
+  out.rootRef = VKRT_TRAV_DONE;
+  LB_TRY(hipMalloc(&out.nodes, std::max<size_t>((size_t)(T > 1 ? T - 1 : 1) * 64, 64)));
+  LB_TRY(hipMalloc(&out.tris, std::max<size_t>((size_t)T * 48, 48)));
+  out.nodeCount = T > 1 ? T - 1 : 0;
+  if(T == 0)
+    return VKRT_OK;
+
+  Temp tmp;
+  uint32_t *dFirstGid, *dFirstIndex, *dVertexOffset;
+  LB_TRY(tmp.alloc(&dFirstGid, instCount + 1));
+  LB_TRY(tmp.alloc(&dFirstIndex, instCount));
+  LB_TRY(tmp.alloc(&dVertexOffset, instCount));
+  LB_TRY(hipMemcpyAsync(dFirstGid, firstGid.data(), (instCount + 1) * 4, hipMemcpyHostToDevice, stream));
+  LB_TRY(hipMemcpyAsync(dFirstIndex, firstIndex.data(), instCount * 4, hipMemcpyHostToDevice, stream));
+  LB_TRY(hipMemcpyAsync(dVertexOffset, vertexOffset.data(), instCount * 4, hipMemcpyHostToDevice, stream));
+
+  float4* triU;
+  float* triBox;
+  unsigned* bounds;
+  unsigned long long *keysA, *keysB;
+  unsigned *valsA, *valsB;
+  LB_TRY(tmp.alloc(&triU, (size_t)T * 3));
+  LB_TRY(tmp.alloc(&triBox, (size_t)T * 6));
+  LB_TRY(tmp.alloc(&bounds, 8));
+  LB_TRY(tmp.alloc(&keysA, T));
+  LB_TRY(tmp.alloc(&keysB, T));
+  LB_TRY(tmp.alloc(&valsA, T));
+  LB_TRY(tmp.alloc(&valsB, T));
+  const unsigned initB[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+  LB_TRY(hipMemcpyAsync(bounds, initB, sizeof initB, hipMemcpyHostToDevice, stream));
+
+  const unsigned B = 256, G = (T + B - 1) / B;
+  FlatArgs A{sc.positions, sc.indices, sc.instances, dFirstGid, dFirstIndex, dVertexOffset, instCount, T};
+  hipLaunchKernelGGL(k_flatten, dim3(G), dim3(B), 0, stream, A, triU, triBox, bounds);
+  hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, T, (const float*)triBox, (const unsigned*)bounds, keysA, valsA);
+  LB_TRY(hipGetLastError());
+
+  size_t sortBytes = 0;
+  LB_TRY(rocprim::radix_sort_pairs(nullptr, sortBytes, keysA, keysB, valsA, valsB, (size_t)T, 0, 63, stream));
+  void* sortTmp;
+  LB_TRY(tmp.alloc((char**)&sortTmp, sortBytes));
+  LB_TRY(rocprim::radix_sort_pairs(sortTmp, sortBytes, keysA, keysB, valsA, valsB, (size_t)T, 0, 63, stream));
+  const unsigned* order = valsB;
+
+  hipLaunchKernelGGL(k_pack, dim3(G), dim3(B), 0, stream, T, order, (const float4*)triU, (float4*)out.tris);
+  LB_TRY(hipGetLastError());
+
+  if(T <= kLeaf)
+  {
+    out.rootRef = (int32_t) ~((0u << 3) | (T - 1u));
+    out.maxDepth = 0;
+    out.nodeCount = 0;
+    LB_TRY(hipStreamSynchronize(stream));
+    return VKRT_OK;
+  }
+
+  int2 *children, *range;
+  int *parentInternal, *parentLeaf;
+  float* nodeBox;
+  unsigned* arrive;
+  unsigned* scalars;  // [0] maxDepth, [1] sah accum (float)
+  LB_TRY(tmp.alloc(&children, T - 1));
+  LB_TRY(tmp.alloc(&range, T - 1));
+  LB_TRY(tmp.alloc(&parentInternal, T - 1));
+  LB_TRY(tmp.alloc(&parentLeaf, T));
+  LB_TRY(tmp.alloc(&nodeBox, (size_t)(T - 1) * 6));
+  LB_TRY(tmp.alloc(&arrive, T - 1));
+  LB_TRY(tmp.alloc(&scalars, 4));
+  LB_TRY(hipMemsetAsync(arrive, 0, (size_t)(T - 1) * 4, stream));
+  LB_TRY(hipMemsetAsync(scalars, 0, 16, stream));
+  hipLaunchKernelGGL(k_hierarchy, dim3(G), dim3(B), 0, stream, (int)T, (const unsigned long long*)keysB, children, range, parentInternal,
+                     parentLeaf);
+  hipLaunchKernelGGL(k_fit, dim3(G), dim3(B), 0, stream, (int)T, order, (const float*)triBox, (const int2*)children,
+                     (const int*)parentInternal, (const int*)parentLeaf, nodeBox, arrive);
+  hipLaunchKernelGGL(k_emit, dim3(G), dim3(B), 0, stream, (int)T, order, (const float*)triBox, (const int2*)children, (const int2*)range,
+                     (const float*)nodeBox, (float4*)out.nodes, (float*)&scalars[1]);
+  hipLaunchKernelGGL(k_depth, dim3(G), dim3(B), 0, stream, (int)T, (const int2*)range, (const int*)parentInternal, (const int*)parentLeaf,
+                     &scalars[0]);
+  LB_TRY(hipGetLastError());
+  unsigned hs[4];
+  float rootBox[6];
+  LB_TRY(hipMemcpyAsync(hs, scalars, 16, hipMemcpyDeviceToHost, stream));
+  LB_TRY(hipMemcpyAsync(rootBox, nodeBox, 24, hipMemcpyDeviceToHost, stream));
+  LB_TRY(hipStreamSynchronize(stream));
+  out.rootRef = 0;
+  out.maxDepth = hs[0];
+  float sah;
+  memcpy(&sah, &hs[1], 4);
+  const float ra = 2.0f * ((rootBox[3] - rootBox[0]) * (rootBox[4] - rootBox[1]) + (rootBox[4] - rootBox[1]) * (rootBox[5] - rootBox[2]) +
+                           (rootBox[5] - rootBox[2]) * (rootBox[3] - rootBox[0]));
+  out.sahCost = ra > 0.0f ? sah / ra : 0.0f;
+  return VKRT_OK;
+}
+
+}  // namespace vkrt

@@ -1,0 +1,328 @@
+// shade.h -- HIP restatement of the reference hit-group semantics:
+//   raytrace.rchit:31-219 (closest hit), raytrace.rmiss:11-19 (miss), gltf.glsl:26-154 (PBR BRDF,
+//   point-light NEE) and the texture() fetches they issue (bilinear, REPEAT, LOD 0:
+//   hello_vulkan.cpp:448-454).  Quirks kept on purpose:
+//   ffnormal unused, ratio from unclamped metalness, emission only at depth 0 or after a specular
+//   bounce, directLight re-reads unclamped material, weight may be negative.
+#pragma once
+#include "device_math.h"
+#include "device_scene.h"
+#include "traverse.h"
+
+// raycommon.glsl:8-19
+struct Payload
+{
+  f3 hitValue;
+  uint32_t seed;
+  uint32_t depth;
+  f3 rayOrigin, rayDirection, weight;
+  bool isSpecular;
+  float lightDist;
+  f3 shadowRayDir;
+};
+
+struct ShadeStats
+{
+  unsigned hits, diffuse, taps;
+};
+
+struct f4 { float x, y, z, w; };
+
+VKRT_DEV int wrapi(int i, int n)
+{
+  int m = i % n;
+  return m < 0 ? m + n : m;
+}
+VKRT_DEV f4 fetchTexel(const DevScene& sc, const DevTexture& tx, int x, int y)
+{
+  const uint32_t p = sc.texels[tx.offset + (uint32_t)y * tx.width + (uint32_t)x];
+  const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
+  f4 o;
+  if(tx.srgb) { o.x = sc.srgbLut[r]; o.y = sc.srgbLut[g]; o.z = sc.srgbLut[b]; }
+  else { o.x = (float)r / 255.0f; o.y = (float)g / 255.0f; o.z = (float)b / 255.0f; }
+  o.w = (float)a / 255.0f;
+  return o;
+}
+VKRT_DEV f4 sampleTex(const DevScene& sc, int texIndex, float u, float v, ShadeStats& st)
+{
+  st.taps++;
+  f4 r;
+  if(sc.textureCount == 0u || texIndex < 0 || texIndex >= (int)sc.textureCount)
+  {
+    r.x = r.y = r.z = r.w = 1.0f;  // 1x1 white dummy (hello_vulkan.cpp:468-472)
+    return r;
+  }
+  const DevTexture tx = sc.textures[texIndex];
+  float fx = u * (float)tx.width - 0.5f;
+  float fy = v * (float)tx.height - 0.5f;
+  if(!(fabsf(fx) < 1.0e9f)) fx = 0.0f;
+  if(!(fabsf(fy) < 1.0e9f)) fy = 0.0f;
+  const float flx = floorf(fx), fly = floorf(fy);
+  const float ax = fx - flx, ay = fy - fly;
+  const int x0 = wrapi((int)flx, (int)tx.width), x1 = wrapi((int)flx + 1, (int)tx.width);
+  const int y0 = wrapi((int)fly, (int)tx.height), y1 = wrapi((int)fly + 1, (int)tx.height);
+  const f4 t00 = fetchTexel(sc, tx, x0, y0), t10 = fetchTexel(sc, tx, x1, y0);
+  const f4 t01 = fetchTexel(sc, tx, x0, y1), t11 = fetchTexel(sc, tx, x1, y1);
+  const float bx = 1.0f - ax, by = 1.0f - ay;
+  r.x = (t00.x * bx + t10.x * ax) * by + (t01.x * bx + t11.x * ax) * ay;
+  r.y = (t00.y * bx + t10.y * ax) * by + (t01.y * bx + t11.y * ax) * ay;
+  r.z = (t00.z * bx + t10.z * ax) * by + (t01.z * bx + t11.z * ax) * ay;
+  r.w = (t00.w * bx + t10.w * ax) * by + (t01.w * bx + t11.w * ax) * ay;
+  return r;
+}
+
+// gltf.glsl:26-32
+VKRT_DEV f3 pbrGetBaseColor(const DevScene& sc, const GltfPBRMaterial& mat, float tu, float tv, ShadeStats& st)
+{
+  f3 color = mk3(mat.pbrBaseColorFactor[0], mat.pbrBaseColorFactor[1], mat.pbrBaseColorFactor[2]);
+  if(mat.pbrBaseColorTexture > -1)
+  {
+    const f4 t = sampleTex(sc, mat.pbrBaseColorTexture, tu, tv, st);
+    color = color * mk3(t.x, t.y, t.z);
+  }
+  return color;
+}
+// gltf.glsl:34-45
+VKRT_DEV void pbrGetMetallicRoughness(const DevScene& sc, const GltfPBRMaterial& mat, float tu, float tv, float& metallic,
+                                      float& roughness, ShadeStats& st)
+{
+  metallic = mat.metallicFactor;
+  roughness = mat.roughnessFactor;
+  if(mat.metallicRoughnessTexture > -1)
+  {
+    const f4 t = sampleTex(sc, mat.metallicRoughnessTexture, tu, tv, st);
+    roughness *= t.y;
+    metallic *= t.z;
+  }
+}
+// gltf.glsl:55-66
+VKRT_DEV float getNDF_GGXTR(f3 N, f3 H, float alpha)
+{
+  float a2 = alpha * alpha;
+  float NH = dot3(N, H);
+  if(NH <= 0.0f)
+    return 0.0f;
+  float NH2 = NH * NH;
+  float d = NH2 * (a2 - 1.0f) + 1.0f;
+  return a2 * VKRT_INV_PI / (d * d + 1e-4f);
+}
+// gltf.glsl:68-78
+VKRT_DEV float getG_SchlickGGX(float NV, float k) { return NV / (NV * (1.0f - k) + k); }
+VKRT_DEV float getG_Smith(f3 N, f3 V, f3 L, float k)
+{
+  float NV = fabsf(dot3(N, V));
+  float NL = fabsf(dot3(N, L));
+  return getG_SchlickGGX(NV, k) * getG_SchlickGGX(NL, k);
+}
+// gltf.glsl:80-83
+VKRT_DEV f3 getF_Schlick(f3 H, f3 V, f3 F0)
+{
+  return F0 + (mk3(1.0f) - F0) * vk_pow5(1.0f - fabsf(dot3(H, V)));
+}
+// gltf.glsl:85-96
+VKRT_DEV f3 getSpecularBRDF_Cook_Torrance(f3 N, f3 H, f3 V, f3 L, f3 F0, float roughness)
+{
+  float alpha = roughness * roughness;
+  float k = (roughness + 1.0f) * (roughness + 1.0f) / 8.0f;
+  float D = getNDF_GGXTR(N, H, alpha);
+  float G = getG_Smith(N, V, L, k);
+  f3 F = getF_Schlick(H, V, F0);
+  float down = 4.0f * fabsf(dot3(V, N)) * fabsf(dot3(L, N)) + 1e-4f;
+  return D * F * G / down;
+}
+// gltf.glsl:98-109
+VKRT_DEV f3 getSpecularBRDF_over_pdf_Cook_Torrance(f3 N, f3 H, f3 V, f3 L, f3 F0, float roughness, float ratio)
+{
+  float k = (roughness + 1.0f) * (roughness + 1.0f) / 8.0f;
+  float pdf = (1.0f - ratio) * dot3(N, H) / (4.0f * dot3(L, H) + 1e-4f);
+  float G = getG_Smith(N, V, L, k);
+  f3 F = getF_Schlick(H, V, F0);
+  float down = 4.0f * fabsf(dot3(V, N)) * fabsf(dot3(L, N)) + 1e-4f;
+  return (F * G / down) / pdf;
+}
+// gltf.glsl:111-134
+VKRT_DEV f3 computePBR_BRDF(const DevScene& sc, f3 N, f3 V, f3 L, f3 H, const GltfPBRMaterial& mat, float tu, float tv,
+                            ShadeStats& st)
+{
+  f3 baseColor = pbrGetBaseColor(sc, mat, tu, tv, st);
+  float metalness, roughness;
+  pbrGetMetallicRoughness(sc, mat, tu, tv, metalness, roughness, st);
+  f3 F0 = mk3(0.04f);
+  F0 = glsl_mix(F0, baseColor, metalness);
+  f3 F = getF_Schlick(H, V, F0);
+  f3 f_cook_torrance = getSpecularBRDF_Cook_Torrance(N, H, V, L, F0, roughness);
+  f3 kD = mk3(1.0f) - F;
+  kD = kD * (1.0f - metalness);
+  f3 f_lambert = baseColor * VKRT_INV_PI;
+  f3 diffuse = kD * f_lambert;
+  return diffuse + f_cook_torrance;
+}
+// gltf.glsl:136-154 (non-point lights: 0, with Li = 0 and cosTheta = 0)
+VKRT_DEV f3 directLight(const DevScene& sc, const GltfLight& light, f3 P, f3 N, f3 V, const GltfPBRMaterial& mat, float tu,
+                        float tv, f3& Li, float& cosTheta, ShadeStats& st)
+{
+  Li = mk3(0.0f);
+  cosTheta = 0.0f;
+  if(light.type == 0)
+  {
+    f3 Ldir = mk3(light.position[0], light.position[1], light.position[2]) - P;
+    float d = length3(Ldir);
+    f3 L = Ldir / d;
+    f3 H = normalize3(L + V);
+    float attenuation = d * d;
+    Li = mk3(light.color[0], light.color[1], light.color[2]) * light.intensity / attenuation;
+    cosTheta = glsl_max(dot3(L, N), 0.0f);
+    if(cosTheta > 0.0f)
+      return computePBR_BRDF(sc, N, V, L, H, mat, tu, tv, st);
+  }
+  return mk3(0.0f);
+}
+
+VKRT_DEV f3 xformPoint(const DevInstance& in, f3 p)
+{
+  f3 r;
+  r.x = ((in.o2w[0] * p.x + in.o2w[1] * p.y) + in.o2w[2] * p.z) + in.o2w[3];
+  r.y = ((in.o2w[4] * p.x + in.o2w[5] * p.y) + in.o2w[6] * p.z) + in.o2w[7];
+  r.z = ((in.o2w[8] * p.x + in.o2w[9] * p.y) + in.o2w[10] * p.z) + in.o2w[11];
+  return r;
+}
+// vec3(n * gl_WorldToObjectEXT): component j = dot(n, column j of W2O)
+VKRT_DEV f3 xformNormal(const DevInstance& in, f3 n)
+{
+  f3 r;
+  r.x = (n.x * in.w2o[0] + n.y * in.w2o[3]) + n.z * in.w2o[6];
+  r.y = (n.x * in.w2o[1] + n.y * in.w2o[4]) + n.z * in.w2o[7];
+  r.z = (n.x * in.w2o[2] + n.y * in.w2o[5]) + n.z * in.w2o[8];
+  return r;
+}
+VKRT_DEV f3 ld3(const float* p, uint32_t i) { return mk3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+// raytrace.rchit:31-219
+VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, f3 worldRayDir, Payload& prd,
+                               ShadeStats& st)
+{
+  st.hits++;
+  const float4 rec = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
+  const uint32_t instId = (uint32_t)__float_as_int(rec.z), primId = (uint32_t)__float_as_int(rec.w);
+  const DevInstance in = sc.instances[instId];
+  const PrimMeshInfo pinfo = sc.primInfo[in.primMesh];  // rchit:34
+  const uint32_t indexOffset = pinfo.indexOffset + 3u * primId;
+  const uint32_t vertexOffset = pinfo.vertexOffset;
+  const uint32_t matIndex = (uint32_t)max(0, pinfo.materialIndex);
+  const uint32_t i0 = sc.indices[indexOffset + 0] + vertexOffset;
+  const uint32_t i1 = sc.indices[indexOffset + 1] + vertexOffset;
+  const uint32_t i2 = sc.indices[indexOffset + 2] + vertexOffset;
+  const f3 b = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);  // rchit:68
+
+  const f3 pos = ld3(sc.positions, i0) * b.x + ld3(sc.positions, i1) * b.y + ld3(sc.positions, i2) * b.z;
+  const f3 worldPos = xformPoint(in, pos);
+  const f3 nrm = normalize3(ld3(sc.normals, i0) * b.x + ld3(sc.normals, i1) * b.y + ld3(sc.normals, i2) * b.z);
+  const f3 worldNrm = normalize3(xformNormal(in, nrm));
+  const float4 tq0 = ((const float4*)sc.tangents)[i0];
+  const float4 tq1 = ((const float4*)sc.tangents)[i1];
+  const float4 tq2 = ((const float4*)sc.tangents)[i2];
+  const f3 tag = normalize3(mk3(tq0.x, tq0.y, tq0.z) * b.x + mk3(tq1.x, tq1.y, tq1.z) * b.y + mk3(tq2.x, tq2.y, tq2.z) * b.z);
+  f3 worldTag = normalize3(xformNormal(in, tag));
+  worldTag = normalize3(worldTag - dot3(worldTag, worldNrm) * worldNrm);
+  const f3 worldBin = tq0.w * cross3(worldNrm, worldTag);
+  const float2 uv0 = ((const float2*)sc.texcoords)[i0];
+  const float2 uv1 = ((const float2*)sc.texcoords)[i1];
+  const float2 uv2 = ((const float2*)sc.texcoords)[i2];
+  const float tu = (uv0.x * b.x + uv1.x * b.y) + uv2.x * b.z;
+  const float tv = (uv0.y * b.x + uv1.y * b.y) + uv2.y * b.z;
+
+  const GltfPBRMaterial mat = sc.materials[matIndex];
+  f3 emittance = mk3(0.0f);
+  if(prd.depth == 0 || prd.isSpecular)  // rchit:83
+  {
+    emittance = mk3(mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]);
+    if(mat.emissiveTexture > -1)
+    {
+      const f4 t = sampleTex(sc, mat.emissiveTexture, tu, tv, st);
+      emittance = emittance * mk3(t.x, t.y, t.z);
+    }
+  }
+  f3 tangent = worldTag, binormal = worldBin;
+  f3 texNormal = worldNrm;
+  if(mat.normalTexture > -1)  // rchit:100-106
+  {
+    const f4 t = sampleTex(sc, mat.normalTexture, tu, tv, st);
+    texNormal = normalize3(mk3(t.x, t.y, t.z) * 2.0f - mk3(1.0f));
+    texNormal = normalize3(tangent * texNormal.x + binormal * texNormal.y + worldNrm * texNormal.z);
+    createCoordinateSystem(texNormal, tangent, binormal);
+  }
+  const f3 baseColor = pbrGetBaseColor(sc, mat, tu, tv, st);
+  float metalness, roughness;
+  pbrGetMetallicRoughness(sc, mat, tu, tv, metalness, roughness, st);
+
+  const f3 rayOrigin = worldPos;
+  f3 rayDirection;
+  float pdf;
+  f3 BRDF;
+  const f3 V = normalize3(-worldRayDir);
+  const f3 N = texNormal;
+
+  const float ratio = 0.5f * (1.0f - metalness);  // rchit:127 (before the clamps)
+  roughness = glsl_clamp(roughness, 0.01f, 0.99f);
+  metalness = glsl_clamp(metalness, 0.01f, 0.99f);
+  const float r1 = rnd(prd.seed);
+  if(r1 < ratio)
+  {
+    st.diffuse++;
+    prd.isSpecular = false;
+    const int random_index = (int)(rnd(prd.seed) * (float)pc.lightsCount);
+    const GltfLight light = sc.lights[random_index];
+    const f3 lightDir = mk3(light.position[0], light.position[1], light.position[2]) - worldPos;
+    const float lightDistance = length3(lightDir);
+    const f3 L = normalize3(lightDir);
+    prd.lightDist = lightDistance;
+    prd.shadowRayDir = L;
+    if(dot3(L, texNormal) <= 0)
+      emittance = emittance + mk3(0.0f);
+    else
+    {
+      f3 Li;
+      float cosTheta;
+      const f3 brdf = directLight(sc, light, worldPos, texNormal, V, mat, tu, tv, Li, cosTheta, st);
+      emittance = emittance + (float)pc.lightsCount * brdf * Li * cosTheta;
+    }
+    rayDirection = normalize3(samplingHemisphere(prd.seed, tangent, binormal, texNormal));
+    pdf = ratio * dot3(rayDirection, texNormal) * VKRT_INV_PI;
+    BRDF = (1.0f - metalness) * baseColor * VKRT_INV_PI;
+  }
+  else
+  {
+    prd.isSpecular = true;
+    const float alpha = roughness * roughness;
+    const f3 h = samplingNDF_GGXTR(prd.seed, alpha * alpha);
+    const f3 H = normalize3(tangent * h.x + binormal * h.y + texNormal * h.z);
+    const f3 L = normalize3(glsl_reflect(-V, H));
+    rayDirection = L;
+    f3 F0 = mk3(0.04f);
+    F0 = glsl_mix(F0, baseColor, metalness);
+    pdf = 1.0f;
+    BRDF = getSpecularBRDF_over_pdf_Cook_Torrance(N, H, V, L, F0, roughness, ratio);
+  }
+  const float cosTheta = dot3(rayDirection, texNormal);
+  prd.rayOrigin = rayOrigin;
+  prd.rayDirection = rayDirection;
+  prd.hitValue = emittance;
+  prd.weight = BRDF * cosTheta / pdf;
+}
+
+// raytrace.rmiss:11-19
+VKRT_DEV void missShader(const PushConstantRay& pc, Payload& prd)
+{
+  if(prd.depth == 0)
+    prd.hitValue = mk3(pc.clearColor[0], pc.clearColor[1], pc.clearColor[2]) * 0.8f;
+  else
+    prd.hitValue = mk3(0.01f);
+  prd.depth = 100;
+}
+
+VKRT_DEV void mat4MulVec4(const float* M, float v0, float v1, float v2, float v3, float* out)
+{
+#pragma unroll
+  for(int i = 0; i < 4; i++)
+    out[i] = ((M[0 + i] * v0 + M[4 + i] * v1) + M[8 + i] * v2) + M[12 + i] * v3;
+}

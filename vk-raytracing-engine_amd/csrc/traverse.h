@@ -1,0 +1,174 @@
+// traverse.h -- software replacement for traceRayEXT (reference raytrace.rgen:64-75 closest hit,
+// :85-97 shadow/any hit): per-lane BVH2 traversal with a per-lane stack in LDS and
+// Moeller-Trumbore on pre-transformed 48-byte triangle records.
+//
+// Result definition (must not depend on the tree): closest hit = smallest t in
+// (tmin, tmax), ties -> smallest flattened triangle id; any hit = exists t in (tmin, tmax).
+// Box tests are conservative (far side padded) so pruning can never remove the defined result.
+#pragma once
+#include "device_math.h"
+#include "device_scene.h"
+
+struct RayHit
+{
+  float t, u, v;
+  int slot;  // index of the triangle record, -1 = miss
+};
+
+VKRT_DEV float safe_inv(float d)
+{
+  const float tiny = 1e-20f;
+  float dd = (fabsf(d) < tiny) ? copysignf(tiny, d) : d;
+  return 1.0f / dd;
+}
+
+// conservative slab test against one child box; returns hit and entry distance
+VKRT_DEV bool box_test(f3 o, f3 id, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float tmax,
+                       float& tnear)
+{
+  float t0x = (lox - o.x) * id.x, t1x = (hix - o.x) * id.x;
+  float t0y = (loy - o.y) * id.y, t1y = (hiy - o.y) * id.y;
+  float t0z = (loz - o.z) * id.z, t1z = (hiz - o.z) * id.z;
+  float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+  float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  tnear = tn;
+  return tn <= tf * 1.0000004f;
+}
+
+// Moeller-Trumbore on (v0,e1,e2); one IEEE division, only for rays inside the triangle.
+VKRT_DEV bool tri_test(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t, float& u, float& v)
+{
+  f3 pvec = fcross3(d, e2);
+  float det = fdot3(e1, pvec);
+  f3 tvec = o - v0;
+  float U = fdot3(tvec, pvec);
+  f3 qvec = fcross3(tvec, e1);
+  float V = fdot3(d, qvec);
+  float T = fdot3(e2, qvec);
+  bool ok;
+  if(det > 0.0f)
+    ok = (U >= 0.0f) && (V >= 0.0f) && (U + V <= det);
+  else if(det < 0.0f)
+    ok = (U <= 0.0f) && (V <= 0.0f) && (U + V >= det);
+  else
+    ok = false;
+  if(!ok)
+    return false;
+  float inv = 1.0f / det;
+  t = T * inv;
+  u = U * inv;
+  v = V * inv;
+  return true;
+}
+
+// stk: this lane's LDS stack column (entry k at stk[k * stride]).
+template <bool COUNT>
+VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* stk, int stride, RayHit& hit,
+                       unsigned& nNodes, unsigned& nTris)
+{
+  const f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  const float4* __restrict__ nodes = sc.nodes;
+  const float4* __restrict__ tris = sc.tris;
+  const int cap = (int)sc.stackCap;
+  float bestT = tmax, bestU = 0.0f, bestV = 0.0f;
+  int bestSlot = -1, bestGid = -1;
+  int cur = sc.rootRef;
+  int sp = 0;
+  // Safety net: a well-formed tree needs at most nodes+leaves steps; a malformed one (builder bug)
+  // must still terminate so the grid always drains.
+  unsigned steps = sc.stepLimit;
+  while(cur != VKRT_TRAV_DONE)
+  {
+    while(cur >= 0)
+    {
+      if(--steps == 0u)
+      {
+        cur = VKRT_TRAV_DONE;
+        break;
+      }
+      const float4 q0 = nodes[cur * VKRT_NODE_QUADS + 0];
+      const float4 q1 = nodes[cur * VKRT_NODE_QUADS + 1];
+      const float4 q2 = nodes[cur * VKRT_NODE_QUADS + 2];
+      const float4 q3 = nodes[cur * VKRT_NODE_QUADS + 3];
+      if(COUNT) nNodes++;
+      float tn0, tn1;
+      const bool h0 = box_test(o, id, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmin, bestT, tn0);
+      const bool h1 = box_test(o, id, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmin, bestT, tn1);
+      const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+      if(h0 && h1)
+      {
+        const bool swap = tn1 < tn0;
+        const int nearC = swap ? c1 : c0, farC = swap ? c0 : c1;
+        if(sp < cap)
+        {
+          stk[sp * stride] = farC;
+          sp++;
+        }
+        cur = nearC;
+      }
+      else if(h0)
+        cur = c0;
+      else if(h1)
+        cur = c1;
+      else
+      {
+        if(sp == 0)
+          cur = VKRT_TRAV_DONE;
+        else
+        {
+          sp--;
+          cur = stk[sp * stride];
+        }
+      }
+    }
+    if(cur != VKRT_TRAV_DONE)
+    {
+      if(--steps == 0u)
+        break;
+      const unsigned code = ~(unsigned)cur;
+      const unsigned first = code >> 3, cnt = (code & 7u) + 1u;
+      bool done = false;
+      for(unsigned k = 0; k < cnt; k++)
+      {
+        const unsigned s = first + k;
+        const float4 a = tris[s * VKRT_TRI_QUADS + 0];
+        const float4 b = tris[s * VKRT_TRI_QUADS + 1];
+        const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+        if(COUNT) nTris++;
+        float t, u, v;
+        if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
+        {
+          if(t > tmin)
+          {
+            if(anyHit)
+            {
+              if(t < tmax)
+              {
+                bestSlot = (int)s;
+                bestT = t;
+                done = true;
+                break;
+              }
+            }
+            else
+            {
+              const int gid = __float_as_int(c.y);
+              if(t < bestT || (t == bestT && gid < bestGid))
+              {
+                bestT = t; bestU = u; bestV = v; bestSlot = (int)s; bestGid = gid;
+              }
+            }
+          }
+        }
+      }
+      if(done || sp == 0)
+        cur = VKRT_TRAV_DONE;
+      else
+      {
+        sp--;
+        cur = stk[sp * stride];
+      }
+    }
+  }
+  hit.t = bestT; hit.u = bestU; hit.v = bestV; hit.slot = bestSlot;
+}

@@ -1,0 +1,539 @@
+// vkrt_api.cpp -- implementation of the C ABI declared in include/vkrt.h (compiled as HIP).
+//
+// Scene upload mirrors HelloVulkan::loadGltfScene's device-local buffers (hello_vulkan.cpp:353-381);
+// vkrt_accel_build stands in for createBottomLevelASGltf/createTopLevelAsGltf (:1001-1047);
+// vkrt_pathtrace stands in for HelloVulkan::pathtrace (:1423-1448).  There is no CPU fallback:
+// without a HIP device the compute entry points fail with VKRT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vkrt.h"
+#include "bvh_host.h"
+#include "device_scene.h"
+#include "kernels.h"
+#include "lbvh.h"
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const char* fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_lastError = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do                                                                                                   \
+  {                                                                                                    \
+    hipError_t e_ = (expr);                                                                            \
+    if(e_ != hipSuccess)                                                                               \
+      return fail(e_ == hipErrorOutOfMemory ? VKRT_ERR_OUT_OF_MEMORY : VKRT_ERR_HIP, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                              \
+  } while(0)
+
+}  // namespace
+
+struct vkrt_scene
+{
+  int device = 0;
+  int cuCount = 256;
+  // host copies (kept like m_gltfScene keeps its vectors)
+  std::vector<float> positions;
+  std::vector<uint32_t> indices;
+  std::vector<vkrt_prim_mesh> primMeshes;
+  std::vector<vkrt_node> nodes;
+  uint32_t lightCount = 0, materialCount = 0;
+  // device allocations
+  std::vector<void*> allocs;
+  DevScene dev{};
+  void* accelNodes = nullptr;
+  void* accelTris = nullptr;
+  bool built = false;
+  vkrt_accel_info info{};
+  unsigned int* workCounter = nullptr;
+  DevCounters* counters = nullptr;
+  hipEvent_t evStart = nullptr, evStop = nullptr;
+  bool timed = false;
+};
+
+namespace {
+
+template <typename T>
+int upload(vkrt_scene* s, const T* src, size_t count, const T** dst)
+{
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  HIP_TRY(hipMalloc(&p, bytes));
+  s->allocs.push_back(p);
+  if(count)
+    HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  *dst = (const T*)p;
+  return VKRT_OK;
+}
+
+int validate(const vkrt_scene_desc* d)
+{
+  if(!d)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "desc is NULL");
+  if(d->struct_size != sizeof(vkrt_scene_desc))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "vkrt_scene_desc.struct_size %u != %zu (ABI mismatch)", d->struct_size,
+                sizeof(vkrt_scene_desc));
+  if(d->vertex_count && (!d->positions || !d->normals || !d->tangents || !d->texcoords0))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "vertex arrays missing");
+  if(d->index_count && !d->indices)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "indices missing");
+  if(d->material_count == 0 || !d->materials)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "at least one material is required (nvh::GltfScene appends a default one)");
+  if(d->light_count == 0 || !d->lights)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "at least one light is required (hello_vulkan.cpp:247 adds 8 fallback lights)");
+  if((d->prim_mesh_count && !d->prim_meshes) || (d->node_count && !d->nodes) || (d->texture_count && !d->textures))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "array pointer missing");
+  for(uint32_t i = 0; i < d->prim_mesh_count; i++)
+  {
+    const vkrt_prim_mesh& p = d->prim_meshes[i];
+    if((uint64_t)p.firstIndex + p.indexCount > d->index_count || (uint64_t)p.vertexOffset + p.vertexCount > d->vertex_count)
+      return fail(VKRT_ERR_INVALID_ARGUMENT, "primMesh %u: range outside the index/vertex arrays", i);
+    if(p.materialIndex >= (int32_t)d->material_count)
+      return fail(VKRT_ERR_INVALID_ARGUMENT, "primMesh %u: materialIndex %d out of range", i, p.materialIndex);
+    const uint32_t triIdx = (p.indexCount / 3) * 3;
+    for(uint32_t k = 0; k < triIdx; k++)
+      if(d->indices[p.firstIndex + k] >= p.vertexCount)
+        return fail(VKRT_ERR_INVALID_ARGUMENT, "primMesh %u: index %u >= vertexCount %u", i, d->indices[p.firstIndex + k],
+                    p.vertexCount);
+  }
+  for(uint32_t i = 0; i < d->node_count; i++)
+    if(d->nodes[i].primMesh < 0 || (uint32_t)d->nodes[i].primMesh >= d->prim_mesh_count)
+      return fail(VKRT_ERR_INVALID_ARGUMENT, "node %u: primMesh %d out of range", i, d->nodes[i].primMesh);
+  for(uint32_t i = 0; i < d->material_count; i++)
+  {
+    const GltfPBRMaterial& m = d->materials[i];
+    const int32_t t[4] = {m.pbrBaseColorTexture, m.metallicRoughnessTexture, m.normalTexture, m.emissiveTexture};
+    for(int k = 0; k < 4; k++)
+      if(t[k] >= (int32_t)d->texture_count && d->texture_count > 0)
+        return fail(VKRT_ERR_INVALID_ARGUMENT, "material %u: texture index %d out of range", i, t[k]);
+  }
+  for(uint32_t i = 0; i < d->texture_count; i++)
+    if(!d->textures[i].rgba8 || d->textures[i].width == 0 || d->textures[i].height == 0)
+      return fail(VKRT_ERR_INVALID_ARGUMENT, "texture %u: empty", i);
+  return VKRT_OK;
+}
+
+void freeAccel(vkrt_scene* s)
+{
+  if(s->accelNodes) (void)hipFree(s->accelNodes);
+  if(s->accelTris) (void)hipFree(s->accelTris);
+  s->accelNodes = s->accelTris = nullptr;
+  s->built = false;
+}
+
+int setDevice(const vkrt_scene* s)
+{
+  HIP_TRY(hipSetDevice(s->device));
+  return VKRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vkrt_abi_version(void) { return VKRT_ABI_VERSION; }
+const char* vkrt_last_error(void) { return g_lastError.c_str(); }
+
+int vkrt_device_count(void)
+{
+  int n = 0;
+  if(hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
+{
+  if(!out)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int rc = validate(d);
+  if(rc != VKRT_OK)
+    return rc;
+  const int ndev = vkrt_device_count();
+  if(ndev <= 0)
+    return fail(VKRT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  if(device < 0 || device >= ndev)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, ndev);
+  vkrt_scene* s = new vkrt_scene();
+  s->device = device;
+  auto bail = [&](int code) {
+    vkrt_scene_destroy(s);
+    return code;
+  };
+  if((rc = setDevice(s)) != VKRT_OK)
+    return bail(rc);
+  hipDeviceProp_t prop;
+  if(hipGetDeviceProperties(&prop, device) == hipSuccess)
+    s->cuCount = prop.multiProcessorCount;
+
+  s->positions.assign(d->positions, d->positions + 3 * (size_t)d->vertex_count);
+  s->indices.assign(d->indices, d->indices + d->index_count);
+  s->primMeshes.assign(d->prim_meshes, d->prim_meshes + d->prim_mesh_count);
+  s->nodes.assign(d->nodes, d->nodes + d->node_count);
+  s->lightCount = d->light_count;
+  s->materialCount = d->material_count;
+
+  DevScene& D = s->dev;
+  if((rc = upload(s, d->positions, 3 * (size_t)d->vertex_count, &D.positions)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, d->normals, 3 * (size_t)d->vertex_count, &D.normals)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, d->tangents, 4 * (size_t)d->vertex_count, &D.tangents)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, d->texcoords0, 2 * (size_t)d->vertex_count, &D.texcoords)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, d->indices, (size_t)d->index_count, &D.indices)) != VKRT_OK) return bail(rc);
+  // ePrimLookup buffer (hello_vulkan.cpp:363-368)
+  std::vector<PrimMeshInfo> lookup(d->prim_mesh_count);
+  for(uint32_t i = 0; i < d->prim_mesh_count; i++)
+    lookup[i] = PrimMeshInfo{d->prim_meshes[i].firstIndex, d->prim_meshes[i].vertexOffset, d->prim_meshes[i].materialIndex};
+  if((rc = upload(s, lookup.data(), lookup.size(), &D.primInfo)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, d->materials, (size_t)d->material_count, &D.materials)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, d->lights, (size_t)d->light_count, &D.lights)) != VKRT_OK) return bail(rc);
+  // instances: object->world rows + inverse (gl_ObjectToWorldEXT / gl_WorldToObjectEXT, rchit:72-76)
+  std::vector<DevInstance> inst(d->node_count);
+  for(uint32_t n = 0; n < d->node_count; n++)
+  {
+    DevInstance& in = inst[n];
+    memset(&in, 0, sizeof in);
+    for(int r = 0; r < 3; r++)
+      for(int c = 0; c < 4; c++)
+        in.o2w[r * 4 + c] = d->nodes[n].worldMatrix[c * 4 + r];
+    vkrt::invert3x3_rows(in.o2w, in.w2o);
+    in.primMesh = d->nodes[n].primMesh;
+  }
+  if((rc = upload(s, inst.data(), inst.size(), &D.instances)) != VKRT_OK) return bail(rc);
+  // textures: RGBA8 pool + table + sRGB decode table
+  std::vector<DevTexture> table(d->texture_count);
+  std::vector<uint32_t> pool;
+  for(uint32_t t = 0; t < d->texture_count; t++)
+  {
+    const vkrt_texture& tx = d->textures[t];
+    table[t] = DevTexture{(uint32_t)pool.size(), tx.width, tx.height, tx.is_srgb ? 1u : 0u};
+    const size_t n = (size_t)tx.width * tx.height;
+    const size_t at = pool.size();
+    pool.resize(at + n);
+    memcpy(&pool[at], tx.rgba8, n * 4);
+  }
+  float lut[256];
+  for(int i = 0; i < 256; i++)
+  {
+    const float c = (float)i / 255.0f;
+    lut[i] = (c <= 0.04045f) ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+  }
+  if((rc = upload(s, table.data(), table.size(), &D.textures)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, pool.data(), pool.size(), &D.texels)) != VKRT_OK) return bail(rc);
+  const float* lutDev = nullptr;
+  if((rc = upload(s, lut, 256, &lutDev)) != VKRT_OK) return bail(rc);
+  D.srgbLut = lutDev;
+  D.textureCount = d->texture_count;
+  D.rootRef = VKRT_TRAV_DONE;
+  D.stackCap = 1;
+  D.stepLimit = 64;
+
+  void* p = nullptr;
+  if(hipMalloc(&p, 64) != hipSuccess) return bail(fail(VKRT_ERR_OUT_OF_MEMORY, "hipMalloc(work counter)"));
+  s->allocs.push_back(p);
+  s->workCounter = (unsigned int*)p;
+  if(hipMalloc(&p, sizeof(DevCounters)) != hipSuccess) return bail(fail(VKRT_ERR_OUT_OF_MEMORY, "hipMalloc(counters)"));
+  s->allocs.push_back(p);
+  s->counters = (DevCounters*)p;
+  if(hipMemset(s->counters, 0, sizeof(DevCounters)) != hipSuccess) return bail(fail(VKRT_ERR_HIP, "hipMemset(counters)"));
+  if(hipEventCreate(&s->evStart) != hipSuccess || hipEventCreate(&s->evStop) != hipSuccess)
+    return bail(fail(VKRT_ERR_HIP, "hipEventCreate"));
+  *out = s;
+  return VKRT_OK;
+}
+
+void vkrt_scene_destroy(vkrt_scene* s)
+{
+  if(!s)
+    return;
+  (void)hipSetDevice(s->device);
+  freeAccel(s);
+  for(void* p : s->allocs)
+    (void)hipFree(p);
+  if(s->evStart) (void)hipEventDestroy(s->evStart);
+  if(s->evStop) (void)hipEventDestroy(s->evStop);
+  delete s;
+}
+
+int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
+{
+  if(!s)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if(flags == 0)
+    flags = VKRT_BUILD_DEFAULT;
+  const bool wantLbvh = (flags & VKRT_BUILD_LBVH_GPU) != 0, wantSah = (flags & VKRT_BUILD_SAH_HOST) != 0;
+  if(wantLbvh == wantSah)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "build_flags must select exactly one of VKRT_BUILD_LBVH_GPU / VKRT_BUILD_SAH_HOST");
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  HIP_TRY(hipStreamSynchronize(stream));  // no trace may be reading the old tree
+  freeAccel(s);
+  const auto t0 = std::chrono::steady_clock::now();
+  s->info = vkrt_accel_info{};
+  s->info.build_flags = wantLbvh ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
+
+  if(wantSah)
+  {
+    std::vector<vkrt::FlatTri> tris;
+    vkrt::flatten_instances(s->positions.data(), s->indices.data(), s->primMeshes.data(), s->nodes.data(),
+                            (uint32_t)s->nodes.size(), tris);
+    vkrt::BuiltBvh bvh;
+    vkrt::build_sah_host(tris, 4, bvh);
+    std::vector<float> packed;
+    vkrt::pack_triangles(tris, bvh.triOrder, packed);
+    const size_t nodeBytes = std::max<size_t>(bvh.nodes.size() * sizeof(float), 64);
+    const size_t triBytes = std::max<size_t>(packed.size() * sizeof(float), 48);
+    HIP_TRY(hipMalloc(&s->accelNodes, nodeBytes));
+    HIP_TRY(hipMalloc(&s->accelTris, triBytes));
+    if(!bvh.nodes.empty())
+      HIP_TRY(hipMemcpyAsync(s->accelNodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    if(!packed.empty())
+      HIP_TRY(hipMemcpyAsync(s->accelTris, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    s->dev.nodes = (const float4*)s->accelNodes;
+    s->dev.tris = (const float4*)s->accelTris;
+    s->dev.triCount = (uint32_t)tris.size();
+    s->dev.rootRef = bvh.rootRef;
+    s->dev.stackCap = bvh.maxDepth + 2;
+    s->info.triangle_count = (uint32_t)tris.size();
+    s->info.node_count = (uint32_t)(bvh.nodes.size() / 16);
+    s->info.max_depth = bvh.maxDepth;
+    s->info.sah_cost = bvh.sahCost;
+    s->info.node_bytes = bvh.nodes.size() * sizeof(float);
+    s->info.triangle_bytes = packed.size() * sizeof(float);
+  }
+  else
+  {
+    vkrt::LbvhResult r;
+    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r);
+    if(rc != VKRT_OK)
+      return fail(rc, "LBVH build failed: %s", r.error.c_str());
+    s->accelNodes = r.nodes;
+    s->accelTris = r.tris;
+    s->dev.nodes = (const float4*)r.nodes;
+    s->dev.tris = (const float4*)r.tris;
+    s->dev.triCount = r.triCount;
+    s->dev.rootRef = r.rootRef;
+    s->dev.stackCap = r.maxDepth + 2;
+    s->info.triangle_count = r.triCount;
+    s->info.node_count = r.nodeCount;
+    s->info.max_depth = r.maxDepth;
+    s->info.sah_cost = r.sahCost;
+    s->info.node_bytes = (uint64_t)r.nodeCount * 64;
+    s->info.triangle_bytes = (uint64_t)r.triCount * 48;
+  }
+  s->dev.stepLimit = 4u * (s->info.node_count + s->info.triangle_count) + 64u;
+  // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
+  if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)
+    return fail(VKRT_ERR_UNSUPPORTED, "BVH depth %u needs a %zu-byte LDS stack per workgroup (limit 64 KiB)", s->info.max_depth,
+                (size_t)s->dev.stackCap * 256 * 4);
+  s->info.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  s->built = true;
+  return VKRT_OK;
+}
+
+int vkrt_accel_get_info(const vkrt_scene* s, vkrt_accel_info* out)
+{
+  if(!s || !out)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(!s->built)
+    return fail(VKRT_ERR_NOT_BUILT, "vkrt_accel_build has not been called");
+  *out = s->info;
+  return VKRT_OK;
+}
+
+uint32_t vkrt_shard_rows(const vkrt_shard* sh)
+{
+  if(!sh)
+    return 0;
+  if(sh->strip_rows == 0 || sh->shard_count <= 1)
+    return (sh->shard_count <= 1 || sh->shard_index == 0) ? sh->full_height : 0;
+  const uint32_t strips = (sh->full_height + sh->strip_rows - 1) / sh->strip_rows;
+  uint32_t rows = 0;
+  for(uint32_t s = sh->shard_index; s < strips; s += sh->shard_count)
+  {
+    const uint32_t y0 = s * sh->strip_rows;
+    rows += std::min(sh->strip_rows, sh->full_height - y0);
+  }
+  return rows;
+}
+
+int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts,
+                   const vkrt_shard* shard, float* image, void* hip_stream)
+{
+  if(!s || !pc || !cam || !shard || !image)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(!s->built)
+    return fail(VKRT_ERR_NOT_BUILT, "vkrt_pathtrace before vkrt_accel_build");
+  if(shard->full_width == 0 || shard->full_height == 0)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "empty launch size");
+  if(shard->shard_count > 1 && (shard->strip_rows == 0 || shard->shard_index >= shard->shard_count))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "bad shard (strip_rows %u, %u of %u)", shard->strip_rows, shard->shard_index,
+                shard->shard_count);
+  if(pc->lightsCount < 0 || (uint32_t)pc->lightsCount > s->lightCount)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "PushConstantRay.lightsCount %d outside [0,%u]", pc->lightsCount, s->lightCount);
+  if(pc->samples < 0 || pc->depth < 0 || pc->depth > 99)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "samples/depth out of range");
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  TraceParams P;
+  memset(&P, 0, sizeof P);
+  P.sc = s->dev;
+  P.pc = *pc;
+  memcpy(P.viewInverse, cam->viewInverse.m, sizeof P.viewInverse);
+  memcpy(P.projInverse, cam->projInverse.m, sizeof P.projInverse);
+  P.seed = opts ? opts->seed : 0u;
+  P.flags = opts ? opts->flags : 0u;
+  P.fullW = shard->full_width;
+  P.fullH = shard->full_height;
+  const bool sharded = shard->shard_count > 1;
+  P.stripRows = sharded ? shard->strip_rows : 0u;
+  P.shardCount = sharded ? shard->shard_count : 1u;
+  P.shardIndex = sharded ? shard->shard_index : 0u;
+  P.localRows = vkrt_shard_rows(shard);
+  P.image = image;
+  P.workCounter = s->workCounter;
+  P.counters = s->counters;
+  if(P.localRows == 0)
+    return VKRT_OK;
+  P.tilesX = (P.fullW + 7) / 8;
+  const uint64_t tiles = (uint64_t)P.tilesX * ((P.localRows + 7) / 8);
+  if(tiles * 64 >= 0xFFFFFFFFull)
+    return fail(VKRT_ERR_UNSUPPORTED, "launch too large");
+  P.tileCount = (uint32_t)tiles;
+
+  const bool count = (P.flags & VKRT_TRACE_COUNT_TRAVERSAL) != 0;
+  const size_t lds = (size_t)P.sc.stackCap * 256 * sizeof(int);
+  int perCU = 0;
+  HIP_TRY(vkrt_pathtrace_occupancy(lds, &perCU));
+  if(perCU < 1)
+    return fail(VKRT_ERR_UNSUPPORTED, "path-trace kernel does not fit a CU with %zu B of LDS", lds);
+  const uint64_t wantBlocks = (tiles * 64 + 255) / 256;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wantBlocks, (uint64_t)s->cuCount * perCU));
+
+  HIP_TRY(hipMemsetAsync(s->workCounter, 0, sizeof(unsigned int), stream));
+  HIP_TRY(hipEventRecord(s->evStart, stream));
+  HIP_TRY(vkrt_launch_pathtrace(P, grid, count, stream));
+  HIP_TRY(hipEventRecord(s->evStop, stream));
+  s->timed = true;
+  return VKRT_OK;
+}
+
+int vkrt_counters_reset(vkrt_scene* s, void* hip_stream)
+{
+  if(!s)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(DevCounters), (hipStream_t)hip_stream));
+  return VKRT_OK;
+}
+
+int vkrt_counters_read(vkrt_scene* s, vkrt_counters* out)
+{
+  if(!s || !out)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  DevCounters h;
+  HIP_TRY(hipMemcpy(&h, s->counters, sizeof h, hipMemcpyDeviceToHost));
+  out->rays_closest = h.v[0]; out->rays_shadow = h.v[1]; out->hits = h.v[2]; out->diffuse_hits = h.v[3];
+  out->tex_taps = h.v[4]; out->pixels = h.v[5]; out->nodes_visited = h.v[6]; out->tris_tested = h.v[7];
+  return VKRT_OK;
+}
+
+int vkrt_last_trace_ms(vkrt_scene* s, float* ms)
+{
+  if(!s || !ms)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(!s->timed)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "no trace has been launched on this scene");
+  HIP_TRY(hipEventSynchronize(s->evStop));
+  HIP_TRY(hipEventElapsedTime(ms, s->evStart, s->evStop));
+  return VKRT_OK;
+}
+
+int vkrt_debug_trace_rays(vkrt_scene* s, uint32_t n, const float* origins, const float* directions, float tmin, float tmax,
+                          int any_hit, float* t, float* u, float* v, int32_t* gid)
+{
+  if(!s || (n && (!origins || !directions || !t || !u || !v || !gid)))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(!s->built)
+    return fail(VKRT_ERR_NOT_BUILT, "vkrt_debug_trace_rays before vkrt_accel_build");
+  if(n == 0)
+    return VKRT_OK;
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  float *dO = nullptr, *dD = nullptr, *dT = nullptr, *dU = nullptr, *dV = nullptr;
+  int* dG = nullptr;
+  const size_t b3 = (size_t)n * 3 * sizeof(float), b1 = (size_t)n * sizeof(float);
+  hipError_t e = hipSuccess;
+  auto tryHip = [&](hipError_t x) { if(e == hipSuccess) e = x; };
+  tryHip(hipMalloc((void**)&dO, b3)); tryHip(hipMalloc((void**)&dD, b3)); tryHip(hipMalloc((void**)&dT, b1));
+  tryHip(hipMalloc((void**)&dU, b1)); tryHip(hipMalloc((void**)&dV, b1)); tryHip(hipMalloc((void**)&dG, b1));
+  if(e == hipSuccess) tryHip(hipMemcpy(dO, origins, b3, hipMemcpyHostToDevice));
+  if(e == hipSuccess) tryHip(hipMemcpy(dD, directions, b3, hipMemcpyHostToDevice));
+  if(e == hipSuccess) tryHip(vkrt_launch_trace_rays(s->dev, n, dO, dD, tmin, tmax, any_hit, dT, dU, dV, dG, nullptr));
+  if(e == hipSuccess) tryHip(hipDeviceSynchronize());
+  if(e == hipSuccess) tryHip(hipMemcpy(t, dT, b1, hipMemcpyDeviceToHost));
+  if(e == hipSuccess) tryHip(hipMemcpy(u, dU, b1, hipMemcpyDeviceToHost));
+  if(e == hipSuccess) tryHip(hipMemcpy(v, dV, b1, hipMemcpyDeviceToHost));
+  if(e == hipSuccess) tryHip(hipMemcpy(gid, dG, b1, hipMemcpyDeviceToHost));
+  (void)hipFree(dO); (void)hipFree(dD); (void)hipFree(dT); (void)hipFree(dU); (void)hipFree(dV); (void)hipFree(dG);
+  if(e != hipSuccess)
+    return fail(VKRT_ERR_HIP, "vkrt_debug_trace_rays: %s", hipGetErrorString(e));
+  return VKRT_OK;
+}
+
+int vkrt_debug_eval_math(int device, int op, uint32_t n, const float* a, const float* b, float* out)
+{
+  if(n && (!a || !b || !out))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(vkrt_device_count() <= 0)
+    return fail(VKRT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  if(n == 0)
+    return VKRT_OK;
+  HIP_TRY(hipSetDevice(device));
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  const size_t bytes = (size_t)n * sizeof(float);
+  hipError_t e = hipSuccess;
+  auto tryHip = [&](hipError_t x) { if(e == hipSuccess) e = x; };
+  tryHip(hipMalloc((void**)&dA, bytes)); tryHip(hipMalloc((void**)&dB, bytes)); tryHip(hipMalloc((void**)&dC, bytes));
+  if(e == hipSuccess) tryHip(hipMemcpy(dA, a, bytes, hipMemcpyHostToDevice));
+  if(e == hipSuccess) tryHip(hipMemcpy(dB, b, bytes, hipMemcpyHostToDevice));
+  if(e == hipSuccess) tryHip(vkrt_launch_eval_math(op, n, dA, dB, dC, nullptr));
+  if(e == hipSuccess) tryHip(hipDeviceSynchronize());
+  if(e == hipSuccess) tryHip(hipMemcpy(out, dC, bytes, hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+  if(e != hipSuccess)
+    return fail(VKRT_ERR_HIP, "vkrt_debug_eval_math: %s", hipGetErrorString(e));
+  return VKRT_OK;
+}
+
+}  // extern "C"

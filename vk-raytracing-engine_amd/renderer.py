@@ -1,0 +1,124 @@
+"""Harness-side wrapper of the C ABI (include/vkrt.h): torch owns device memory and streams,
+libvkrt.so does all the work.  Mirrors the call order of the reference's main():
+loadGltfScene -> createBottomLevelASGltf/createTopLevelAsGltf -> per frame pathtrace
+(main.cpp:226-240, 504-508)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import LIB_PATH, abi
+
+_lib = None
+
+
+def load_library():
+    """Load libvkrt.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: build it with __graft_entry__.build() "
+                               "(there is no CPU fallback for the ray-tracing path)")
+        _lib = abi.declare_vkrt(C.CDLL(LIB_PATH))
+        if _lib.vkrt_abi_version() != 1:
+            raise RuntimeError("libvkrt.so ABI version mismatch")
+    return _lib
+
+
+class VkrtError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise VkrtError(f"{what} failed ({rc}): {load_library().vkrt_last_error().decode()}")
+
+
+def whole_image_shard(width, height):
+    return abi.Shard(width, height, 0, 1, 0)
+
+
+class Renderer:
+    def __init__(self, flat, device=0, build="sah"):
+        self.lib = load_library()
+        self.device = device
+        desc, keep = flat.to_desc()
+        h = C.c_void_p()
+        _check(self.lib.vkrt_scene_create(C.byref(desc), device, C.byref(h)), "vkrt_scene_create")
+        self._h = h
+        del keep
+        self.lights_count = int(flat.lights.shape[0])
+        self.build(build)
+
+    def build(self, kind="sah"):
+        flags = {"sah": abi.VKRT_BUILD_SAH_HOST, "lbvh": abi.VKRT_BUILD_LBVH_GPU}[kind]
+        _check(self.lib.vkrt_accel_build(self._h, flags, None), "vkrt_accel_build")
+        self.build_kind = kind
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vkrt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def accel_info(self):
+        info = abi.AccelInfo()
+        _check(self.lib.vkrt_accel_get_info(self._h, C.byref(info)), "vkrt_accel_get_info")
+        return {n: getattr(info, n) for n, _ in info._fields_}
+
+    def shard_rows(self, shard):
+        return int(self.lib.vkrt_shard_rows(C.byref(shard)))
+
+    def pathtrace(self, pc, cam, width, height, seed=0, flags=0, shard=None, image=None, stream=None):
+        """One launch (one frame).  image: torch float32 CUDA tensor [rows, width, 4] (in/out when pc.frame > 0)."""
+        import torch
+
+        shard = shard or whole_image_shard(width, height)
+        rows = self.shard_rows(shard)
+        if image is None:
+            image = torch.zeros((rows, width, 4), dtype=torch.float32, device=f"cuda:{self.device}")
+        assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous() and tuple(image.shape) == (rows, width, 4)
+        if stream is None:
+            stream = torch.cuda.current_stream(image.device)
+        opts = abi.TraceOpts(seed & 0xFFFFFFFF, flags)
+        _check(self.lib.vkrt_pathtrace(self._h, C.byref(pc), C.byref(cam), C.byref(opts), C.byref(shard),
+                                       C.c_void_p(image.data_ptr()), C.c_void_p(stream.cuda_stream)), "vkrt_pathtrace")
+        return image
+
+    def reset_counters(self, stream=None):
+        _check(self.lib.vkrt_counters_reset(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None),
+               "vkrt_counters_reset")
+
+    def counters(self):
+        c = abi.Counters()
+        _check(self.lib.vkrt_counters_read(self._h, C.byref(c)), "vkrt_counters_read")
+        return c.as_dict()
+
+    def last_trace_ms(self):
+        ms = C.c_float()
+        _check(self.lib.vkrt_last_trace_ms(self._h, C.byref(ms)), "vkrt_last_trace_ms")
+        return float(ms.value)
+
+    def trace_rays(self, origins, directions, tmin=0.001, tmax=10000.0, any_hit=False):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t, u, v = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        gid = np.zeros(n, np.int32)
+        _check(self.lib.vkrt_debug_trace_rays(self._h, n, o.ctypes.data, d.ctypes.data, tmin, tmax, 1 if any_hit else 0,
+                                              t.ctypes.data, u.ctypes.data, v.ctypes.data, gid.ctypes.data), "vkrt_debug_trace_rays")
+        return t, u, v, gid
+
+
+def eval_math(op, a, b=None, device=0):
+    lib = load_library()
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(a if b is None else b, np.float32)
+    out = np.zeros_like(a)
+    _check(lib.vkrt_debug_eval_math(device, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data), "vkrt_debug_eval_math")
+    return out
