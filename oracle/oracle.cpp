@@ -1228,7 +1228,7 @@ void orc_eval_shade(uint32_t n, const float* in, float* out)
     m.metallicFactor = p[19]; m.roughnessFactor = p[20];
     for(int k = 0; k < 3; k++) m.emissiveFactor[k] = p[21 + k];
     m.pbrBaseColorTexture = m.metallicRoughnessTexture = m.normalTexture = m.emissiveTexture = -1;
-    GltfLight& L = s.lights[0];
+    GltfLight L;
     for(int k = 0; k < 3; k++) { L.position[k] = p[24 + k]; L.color[k] = p[27 + k]; }
     L.intensity = p[30];
     uint32_t bits[4];
@@ -1240,18 +1240,8 @@ void orc_eval_shade(uint32_t n, const float* in, float* out)
     Payload prd;
     memset(&prd, 0, sizeof prd);
     prd.seed = bits[0]; prd.depth = bits[1]; prd.isSpecular = bits[2] != 0;
-    // lightsCount may exceed 1 for the NEE scale factor; the light index is forced to 0 by
-    // evaluating with a single light whenever int(rnd*lightsCount) would pick another one.
-    int32_t lc = pc.lightsCount;
-    {
-      uint32_t probe = prd.seed;
-      float r1 = rnd(probe);
-      (void)r1;
-      uint32_t probe2 = probe;
-      int idx = (int)(rnd(probe2) * (float)lc);
-      GltfLight Lc = s.lights[0];
-      if(idx != 0) s.lights.resize((size_t)idx + 1, Lc);
-    }
+    // whichever index int(rnd*lightsCount) picks, it finds this record's light
+    s.lights.assign((size_t)std::max(1, pc.lightsCount), L);
     shadeSurface(cx, pc, m, sf, rd, prd);
     o[0] = prd.hitValue.x; o[1] = prd.hitValue.y; o[2] = prd.hitValue.z;
     o[3] = prd.rayOrigin.x; o[4] = prd.rayOrigin.y; o[5] = prd.rayOrigin.z;

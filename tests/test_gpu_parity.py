@@ -77,7 +77,7 @@ def test_closest_hit_rays_match_oracle(renderers, cornell_oracle, kind):
     t1, u1, v1, g1 = renderers[kind].trace_rays(o, d)
     assert np.array_equal(g0, g1)
     hit = g0 >= 0
-    assert hit.mean() > 0.9
+    assert hit.mean() > 0.7
     for a, b in ((t0, t1), (u0, u1), (v0, v1)):
         assert np.array_equal(a[hit].view(np.uint32), b[hit].view(np.uint32))
 

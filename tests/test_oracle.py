@@ -1,0 +1,181 @@
+"""Pins the CPU oracle (oracle/oracle.cpp): integer KATs, cross-restatement agreement, brute force
+vs BVH, analytic images.  The reference ships no golden vectors, so these are the
+pins the oracle has ("parity unpinned" w.r.t. the Vulkan reference itself)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py
+from conftest import GOLDEN, default_camera
+from vkrt_amd.flat_scene import make_push_constants
+
+
+def test_prng_known_answers():
+    kat = json.load(open(os.path.join(GOLDEN, "prng_kat.json")))
+    for a, b, want in kat["tea"] + kat["survey_appendix_c"]["tea"]:
+        assert oracle_py.tea(a, b) == want
+    for rec in kat["lcg"]:
+        got = oracle_py.lcg_sequence(rec["start"], len(rec["seq"]))
+        for (s, bits, r), (ws, wb) in zip(got, rec["seq"]):
+            assert (s, bits) == (ws, wb)
+            assert r == wb / 16777216.0  # exact: 24-bit integer / 2^24
+    sv = kat["survey_appendix_c"]
+    got = oracle_py.lcg_sequence(0, 3)
+    assert [[g[0], g[1]] for g in got] == sv["lcg_from_0"]
+    chain = [g[2] for g in oracle_py.lcg_sequence(oracle_py.tea(0, 0), 4)]
+    assert chain == sv["rnd_chain_from_tea00"]
+
+
+def test_seed_index_collisions_match_survey():
+    """raytrace.rgen:27 uses y*x + x: only 283,600 distinct indices at 1280x720."""
+    kat = json.load(open(os.path.join(GOLDEN, "prng_kat.json")))["survey_appendix_c"]["distinct_seed_indices"]
+    for (w, h), want in (((1280, 720), kat["1280x720"]), ((256, 256), kat["256x256"])):
+        y, x = np.mgrid[0:h, 0:w].astype(np.uint64)
+        assert len(np.unique((y * x + x) & 0xFFFFFFFF)) == want
+
+
+def test_sincos_profile_accuracy():
+    """The profile's sin/cos stay within 2 ulp-ish of the true functions over the sampled range."""
+    x = (np.arange(0, 1 << 24, 37, dtype=np.float64) / 16777216.0 * 6.2831855).astype(np.float32)
+    s, c = oracle_py.eval_math(0, x), oracle_py.eval_math(1, x)
+    assert np.max(np.abs(s - np.sin(x.astype(np.float64)))) < 2.5e-7
+    assert np.max(np.abs(c - np.cos(x.astype(np.float64)))) < 2.5e-7
+    xs = np.linspace(0, 1, 1001, dtype=np.float32)
+    p = oracle_py.eval_math(4, xs)
+    assert np.allclose(p, xs.astype(np.float64) ** 5, rtol=3e-7, atol=1e-30)
+
+
+def test_shading_agrees_with_numpy_restatement():
+    import np_shading
+
+    rec = np_shading.random_records(20000, np.random.default_rng(5))
+    a = oracle_py.eval_shade(rec)
+    b = np_shading.shade(rec)
+    # discrete outputs are exact: lobe choice, PRNG state, ray origin
+    assert np.array_equal(a[:, 12], b[:, 12])
+    assert np.array_equal(a[:, 17].view(np.uint32), b[:, 17].view(np.uint32))
+    assert np.array_equal(a[:, 3:6], b[:, 3:6])
+    for lo, hi, name in ((0, 3, "hitValue"), (6, 9, "rayDirection"), (9, 12, "weight"), (13, 14, "lightDist"), (14, 17, "shadowRayDir")):
+        x, y = a[:, lo:hi].astype(np.float64), b[:, lo:hi].astype(np.float64)
+        scale = np.maximum(np.abs(x), np.abs(y)).max(axis=1, keepdims=True) + 1e-3
+        err = np.abs(x - y) / scale
+        # a handful of ill-conditioned samples (grazing specular pdf) may differ more
+        assert np.quantile(err, 0.999) < 2e-4, (name, float(np.quantile(err, 0.999)))
+        assert np.median(err) < 2e-6, (name, float(np.median(err)))
+
+
+def test_camera_ray_matches_numpy():
+    import camera_np
+
+    W, H = 1280, 720
+    vp, vi, pi = camera_np.global_uniforms(width=W, height=H)
+    cam = default_camera(W, H)
+    for (x, y) in ((0, 0), (W - 1, H - 1), (640, 360), (17, 700)):
+        o, d = oracle_py.camera_ray(cam, x, y, W, H)
+        ndc = np.array([(x + 0.5) / W * 2 - 1, (y + 0.5) / H * 2 - 1, 1.0, 1.0])
+        tgt = pi.astype(np.float64) @ ndc
+        dd = vi.astype(np.float64) @ np.append(tgt[:3] / np.linalg.norm(tgt[:3]), 0.0)
+        assert np.allclose(o, [0, 0, 15], atol=1e-5)
+        assert np.allclose(d, dd[:3], atol=2e-6)
+    # row 0 is the top of the image (perspectiveVK flips Y)
+    _, d_top = oracle_py.camera_ray(cam, 640, 0, W, H)
+    assert d_top[1] > 0
+
+
+def test_bruteforce_equals_bvh_config1(cornell_oracle, cornell_flat):
+    """BASELINE config 1 (cornell 256x256, 1 spp, depth 1): BVH-independent result."""
+    W = H = 256
+    cam = default_camera(W, H)
+    pc = make_push_constants(samples=1, depth=1, frame=0, lights_count=1)
+    a, ca = cornell_oracle.render(pc, cam, W, H, seed=0, use_bvh=True)
+    rows = np.arange(0, H, 4, dtype=np.uint32)  # every 4th row by brute force (time bound)
+    b, cb = cornell_oracle.render(pc, cam, W, H, seed=0, use_bvh=False, rows=rows)
+    assert np.array_equal(a[rows].view(np.uint32), b.view(np.uint32))
+    assert not np.isnan(a).any()
+    # depth-1 analytic structure: alpha forced to 1, background = clearColor*0.8
+    assert np.all(a[..., 3] == 1.0)
+    assert np.all(a[0, 0, :3] == np.float32(0.8))
+    assert ca["rays_closest"] == W * H and ca["pixels"] == W * H
+    assert ca["rays_shadow"] == ca["diffuse_hits"]
+
+
+def test_bruteforce_equals_bvh_multibounce(cornell_oracle):
+    W, H = 96, 64
+    cam = default_camera(W, H)
+    pc = make_push_constants(samples=3, depth=4, frame=2, lights_count=1)
+    img0 = np.full((H, W, 4), 0.25, np.float32)
+    a, _ = cornell_oracle.render(pc, cam, W, H, seed=11, image=img0.copy(), use_bvh=True)
+    b, _ = cornell_oracle.render(pc, cam, W, H, seed=11, image=img0.copy(), use_bvh=False)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_ray_queries_bruteforce_equals_bvh(cornell_oracle):
+    rng = np.random.default_rng(3)
+    o = rng.uniform(-4.5, 4.5, (3000, 3)).astype(np.float32)
+    d = rng.standard_normal((3000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0, u0, v0, g0, _ = cornell_oracle.trace_rays(o, d, use_bvh=True)
+    t1, u1, v1, g1, _ = cornell_oracle.trace_rays(o, d, use_bvh=False)
+    assert np.array_equal(g0, g1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    _, _, _, a0, _ = cornell_oracle.trace_rays(o, d, tmax=2.5, any_hit=True, use_bvh=True)
+    _, _, _, a1, _ = cornell_oracle.trace_rays(o, d, tmax=2.5, any_hit=True, use_bvh=False)
+    assert np.array_equal(a0, a1)
+
+
+def test_miss_only_image(cornell_oracle):
+    """raytrace.rmiss:15 -- looking away from the scene every pixel is clearColor*0.8."""
+    W, H = 40, 30
+    cam = default_camera(W, H, eye=(0, 0, 15), center=(0, 0, 30))
+    pc = make_push_constants(samples=2, depth=4, frame=0, lights_count=1, clear_color=(0.25, 0.5, 1.0, 1.0))
+    img, c = cornell_oracle.render(pc, cam, W, H, seed=1)
+    want = np.array([np.float32(0.25) * np.float32(0.8), np.float32(0.5) * np.float32(0.8), np.float32(0.8), 1.0], np.float32)
+    assert np.all(img == want)
+    assert c["rays_closest"] == W * H * 2 and c["hits"] == 0 and c["rays_shadow"] == 0
+
+
+def test_frame_accumulation_is_mix(cornell_oracle):
+    """raytrace.rgen:136-141: frame>0 blends new into old with a = 1/(frame+1)."""
+    W, H = 32, 24
+    cam = default_camera(W, H)
+    pc1 = make_push_constants(samples=1, depth=2, frame=3, lights_count=1)
+    old = np.full((H, W, 4), 0.5, np.float32)
+    a, _ = cornell_oracle.render(pc1, cam, W, H, seed=4, image=old.copy())
+    zero = np.zeros((H, W, 4), np.float32)
+    b, _ = cornell_oracle.render(pc1, cam, W, H, seed=4, image=zero.copy())  # = new * a
+    al = np.float32(1.0) / np.float32(4.0)
+    want = old[..., :3] * (np.float32(1) - al) + (b[..., :3] / al) * al
+    assert np.allclose(a[..., :3], want, rtol=1e-6, atol=1e-7)
+
+
+def test_texture_sampler_bilinear_repeat_srgb(cornell_flat):
+    import copy
+
+    flat = copy.copy(cornell_flat)
+    rng = np.random.default_rng(0)
+    tex = rng.integers(0, 256, (4, 8, 4), dtype=np.uint8)
+    flat.textures = [dict(rgba8=tex, is_srgb=False), dict(rgba8=tex, is_srgb=True)]
+    s = oracle_py.OracleScene(flat, build_bvh=False)
+    # texel centres reproduce the texel; REPEAT wraps
+    uv = np.array([[(2 + 0.5) / 8, (1 + 0.5) / 4], [(2 + 0.5) / 8 + 3.0, (1 + 0.5) / 4 - 2.0]], np.float32)
+    out = s.sample_texture(0, uv)
+    assert np.allclose(out[0], tex[1, 2] / 255.0, atol=1e-6) and np.allclose(out[1], out[0], atol=1e-5)
+    # halfway between two texels = their mean
+    mid = s.sample_texture(0, np.array([[3.0 / 8, 1.5 / 4]], np.float32))[0]
+    assert np.allclose(mid, (tex[1, 2].astype(np.float64) + tex[1, 3]) / 2 / 255.0, atol=1e-6)
+    # sRGB decode on rgb, linear alpha
+    c = tex[1, 2].astype(np.float64) / 255.0
+    lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    o = s.sample_texture(1, uv[:1])[0]
+    assert np.allclose(o[:3], lin[:3], atol=1e-6) and np.isclose(o[3], c[3], atol=1e-6)
+    # out-of-range texture index -> 1x1 white dummy
+    assert np.all(s.sample_texture(7, uv[:1]) == 1.0)
+
+
+def test_full_sweep_sah_tree_is_valid(cornell_oracle):
+    info = cornell_oracle.bvh_info()
+    assert info["leaves"] == info["nodes"] + 1
+    assert info["max_depth"] < 64
+    v, ids = cornell_oracle.triangles()
+    assert len(v) == 16732 and np.array_equal(ids[:, 0], np.arange(16732))

@@ -16,6 +16,10 @@ def load_library():
     """Load libvkrt.so; fails loudly when the HIP extension has not been built."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; it must be the first HIP runtime mapped into the
+        # process (loading /opt/rocm's copy first leaves torch with "No HIP GPUs are available").
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} missing: build it with __graft_entry__.build() "
                                "(there is no CPU fallback for the ray-tracing path)")
