@@ -231,3 +231,63 @@ def test_traversal_counters_instrumented(renderers, cornell_oracle, cornell_flat
     # different trees (binned vs full-sweep SAH), same order of magnitude of work per ray
     assert 0.5 < c["nodes_visited"] / cref["nodes_visited"] < 2.0
     assert 0.3 < c["tris_tested"] / cref["tris_tested"] < 3.0
+
+
+# ---- Sponza-class atrium (textured, 8 fallback lights, instanced meshes) -------------------------------
+@pytest.fixture(scope="module")
+def atrium_small():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import atrium
+
+    flat, info = atrium.build_atrium(20000, seed=3, with_textures=True)
+    return flat, info, atrium.DEFAULT_CAMERA
+
+
+@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+def test_atrium_small_textured_full_image(atrium_small, kind):
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat, info, camkw = atrium_small
+    W, H = 320, 180
+    cam = default_camera(W, H, **camkw)
+    pc = make_push_constants(samples=4, depth=8, frame=1, lights_count=len(flat.lights))
+    orc = oracle_py.OracleScene(flat)
+    old = np.full((H, W, 4), 0.125, np.float32)
+    ref, cref = orc.render(pc, cam, W, H, seed=21, image=old.copy())
+    assert cref["tex_taps"] > 0
+    import torch
+
+    r = Renderer(flat, device=0, build=kind)
+    r.reset_counters()
+    img = r.pathtrace(pc, cam, W, H, seed=21, image=torch.from_numpy(old.copy()).cuda()).cpu().numpy()
+    c = r.counters()
+    r.close()
+    assert rmse(img, ref) < RMSE_TOL
+    assert mismatch_fraction(img, ref) < 1e-4
+    assert abs(c["tex_taps"] - cref["tex_taps"]) <= 64 and abs(c["rays_shadow"] - cref["rays_shadow"]) <= 16
+
+
+def test_config3_full_size_rows_sample():
+    """BASELINE config 3 at full size (262k-triangle atrium, 1920x1080, 16 spp, depth 8): the GPU frame
+    against oracle-rendered sample rows (the oracle cannot render the whole frame in test time)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import atrium
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat, info = atrium.build_atrium(262144, seed=1, with_textures=True)
+    W, H = 1920, 1080
+    cam = default_camera(W, H, **atrium.DEFAULT_CAMERA)
+    pc = make_push_constants(samples=16, depth=8, frame=0, lights_count=len(flat.lights))
+    rows = np.linspace(0, H - 1, 24).astype(np.uint32)
+    ref, _ = oracle_py.OracleScene(flat).render(pc, cam, W, H, seed=0, rows=rows, threads=min(16, os.cpu_count() or 1))
+    r = Renderer(flat, device=0, build="sah")
+    img = r.pathtrace(pc, cam, W, H, seed=0).cpu().numpy()[rows]
+    r.close()
+    assert rmse(img, ref) < RMSE_TOL
+    assert mismatch_fraction(img, ref) < 1e-4
