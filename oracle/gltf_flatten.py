@@ -206,8 +206,8 @@ def load_gltf(path, image_decoder=None):
                     fn = np.cross(pos[tri[:, 1]] - pos[tri[:, 0]], pos[tri[:, 2]] - pos[tri[:, 0]])
                     with np.errstate(invalid="ignore", divide="ignore"):
                         fn = fn / np.sqrt(np.sum(fn * fn, axis=1, keepdims=True))
-                    for k in range(3):
-                        nrm[tri[:, k]] = fn
+                    # sequential semantics: a later triangle overwrites the normals of shared vertices
+                    nrm[tri.reshape(-1)] = np.repeat(fn, 3, axis=0)
                 uv = _accessor(g, bufs, attr["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in attr else np.zeros((vc, 2), np.float32)
                 if "TANGENT" in attr:
                     tan = _accessor(g, bufs, attr["TANGENT"]).astype(np.float32)

@@ -1,0 +1,241 @@
+// hello_vkrt.cpp -- see hello_vkrt.h.  Thin: every compute step is a C-ABI call into libvkrt.so.
+#include "hello_vkrt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+#include "json_mini.h"
+
+namespace vkrt_host {
+
+void HelloVkrt::check(int rc, const char* what) const
+{
+  if(rc != VKRT_OK)
+    throw std::runtime_error(std::string(what) + ": " + vkrt_last_error());
+}
+
+void HelloVkrt::setup(int width, int height)
+{
+  m_size.width = width;
+  m_size.height = height;
+  CameraManip.setWindowSize(width, height);
+}
+
+void HelloVkrt::loadGltfScene(const std::string& filename) { loadScene(loadGltf(filename)); }
+
+void HelloVkrt::loadScene(const GltfScene& scene)
+{
+  if(m_scene)
+  {
+    vkrt_scene_destroy(m_scene);
+    m_scene = nullptr;
+  }
+  m_gltfScene = scene;
+  std::vector<vkrt_texture> tex;
+  const vkrt_scene_desc d = m_gltfScene.desc(tex);
+  check(vkrt_scene_create(&d, m_device, &m_scene), "vkrt_scene_create");
+  m_pcRay.lightsCount = (int32_t)m_gltfScene.m_lights.size();  // hello_vulkan.cpp:323-324
+}
+
+void HelloVkrt::initRayTracing()
+{
+  // hello_vulkan.cpp:911-915
+  m_pcRay.samples = 1;
+  m_pcRay.depth = 3;
+  m_pcRay.useShadows = 1;
+  m_pcRay.useAO = 1;
+  m_pcRay.useGI = 0;
+}
+
+void HelloVkrt::createBottomLevelASGltf()
+{
+  if(!m_scene)
+    throw std::runtime_error("createBottomLevelASGltf before loadGltfScene");
+  m_blasRequested = true;  // one BLAS per primMesh in the reference; built together with the TLAS here
+}
+
+void HelloVkrt::createTopLevelAsGltf()
+{
+  if(!m_scene || !m_blasRequested)
+    throw std::runtime_error("createTopLevelAsGltf before createBottomLevelASGltf");
+  check(vkrt_accel_build(m_scene, m_buildFlags, nullptr), "vkrt_accel_build");
+}
+
+void HelloVkrt::createOffscreenRender()
+{
+  if(m_offscreenColor)
+  {
+    (void)hipFree(m_offscreenColor);
+    m_offscreenColor = nullptr;
+  }
+  const size_t bytes = (size_t)m_size.width * m_size.height * 4 * sizeof(float);
+  if(hipSetDevice(m_device) != hipSuccess || hipMalloc((void**)&m_offscreenColor, bytes) != hipSuccess)
+    throw std::runtime_error("createOffscreenRender: hipMalloc failed");
+  (void)hipMemset(m_offscreenColor, 0, bytes);
+}
+
+void HelloVkrt::updateUniformBuffer() { m_hostUBO = makeGlobalUniforms(CameraManip, m_size.width, m_size.height); }
+
+void HelloVkrt::resetFrame() { m_pcRay.frame = -1; }
+
+void HelloVkrt::updateFrame()
+{
+  const vkrt_mat4 m = CameraManip.getMatrix();
+  const float fov = CameraManip.getFov();
+  if(!m_refValid || memcmp(&m_refCamMatrix, &m, sizeof m) != 0 || m_refFov != fov)
+  {
+    resetFrame();
+    m_refCamMatrix = m;
+    m_refFov = fov;
+    m_refValid = true;
+  }
+  m_pcRay.frame++;
+}
+
+void HelloVkrt::pathtrace(const float clearColor[4])
+{
+  if(m_stopAtMaxFrames && m_pcRay.frame >= m_maxFrames)
+    return;
+  if(!m_scene || !m_offscreenColor)
+    throw std::runtime_error("pathtrace before scene/offscreen image creation");
+  for(int k = 0; k < 4; k++) m_pcRay.clearColor[k] = clearColor[k];
+  const vkrt_trace_opts opts{m_seed, m_traceFlags};
+  const vkrt_shard shard{(uint32_t)m_size.width, (uint32_t)m_size.height, 0, 1, 0};
+  check(vkrt_pathtrace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, m_offscreenColor, nullptr), "vkrt_pathtrace");
+}
+
+void HelloVkrt::onResize(int w, int h)
+{
+  setup(w, h);
+  resetFrame();
+  createOffscreenRender();
+}
+
+void HelloVkrt::destroyResources()
+{
+  if(m_scene) vkrt_scene_destroy(m_scene);
+  m_scene = nullptr;
+  if(m_offscreenColor) (void)hipFree(m_offscreenColor);
+  m_offscreenColor = nullptr;
+}
+
+void HelloVkrt::downloadImage(std::vector<float>& rgba) const
+{
+  rgba.resize((size_t)m_size.width * m_size.height * 4);
+  if(hipDeviceSynchronize() != hipSuccess ||
+     hipMemcpy(rgba.data(), m_offscreenColor, rgba.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    throw std::runtime_error("downloadImage: hipMemcpy failed");
+}
+
+vkrt_counters HelloVkrt::counters()
+{
+  vkrt_counters c{};
+  check(vkrt_counters_read(m_scene, &c), "vkrt_counters_read");
+  return c;
+}
+vkrt_accel_info HelloVkrt::accelInfo() const
+{
+  vkrt_accel_info i{};
+  check(vkrt_accel_get_info(m_scene, &i), "vkrt_accel_get_info");
+  return i;
+}
+float HelloVkrt::lastTraceMs()
+{
+  float ms = 0;
+  check(vkrt_last_trace_ms(m_scene, &ms), "vkrt_last_trace_ms");
+  return ms;
+}
+
+// ---- config.json ---------------------------------------------------------------------------------------
+AppConfig parseConfig(const std::string& text)
+{
+  const Json j = Json::parse(text);
+  AppConfig c;
+  // mandatory keys, exactly the reference's (main.cpp:139-144)
+  for(const char* k : {"scenes", "scene", "vsync", "width", "height"})
+    if(!j.has(k))
+      throw std::runtime_error(std::string("config.json: missing key \"") + k + "\"");
+  for(size_t i = 0; i < j["scenes"].size(); i++) c.scenes.push_back(j["scenes"][i].string());
+  c.scene = j["scene"].integer();
+  c.vsync = j["vsync"].boolean();
+  c.width = j["width"].integer();
+  c.height = j["height"].integer();
+  if(c.scene < 0 || (size_t)c.scene >= c.scenes.size())
+    throw std::runtime_error("config.json: \"scene\" index out of range");
+  if(c.width <= 0 || c.height <= 0)
+    throw std::runtime_error("config.json: bad width/height");
+  // optional keys (stand-ins for the ImGui panel state)
+  c.samples = j["samples"].integer(c.samples);
+  c.depth = j["depth"].integer(c.depth);
+  c.frames = j["frames"].integer(c.frames);
+  c.seed = j["seed"].integer(c.seed);
+  c.seedPerFrame = j["seedPerFrame"].boolean(c.seedPerFrame);
+  c.build = j["build"].string(c.build);
+  c.output = j["output"].string("");
+  if(j.has("clearColor"))
+    for(int k = 0; k < 4; k++) c.clearColor[k] = (float)j["clearColor"][(size_t)k].number(1.0);
+  if(j.has("camera"))
+  {
+    const Json& cam = j["camera"];
+    c.hasCamera = true;
+    auto v3 = [&](const char* k, Vec3 d) {
+      if(!cam.has(k)) return d;
+      return Vec3{(float)cam[k][0].number(), (float)cam[k][1].number(), (float)cam[k][2].number()};
+    };
+    c.eye = v3("eye", c.eye);
+    c.center = v3("center", c.center);
+    c.up = v3("up", c.up);
+    c.fov = (float)cam["fov"].number(c.fov);
+  }
+  return c;
+}
+
+AppConfig loadConfig(const std::string& path)
+{
+  std::ifstream f(path);
+  if(!f)
+    throw std::runtime_error("cannot open " + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return parseConfig(ss.str());
+}
+
+// ---- image writers ---------------------------------------------------------------------------------------
+void writePPM(const std::string& path, const std::vector<float>& rgba, int w, int h)
+{
+  std::ofstream f(path, std::ios::binary);
+  f << "P6\n" << w << " " << h << "\n255\n";
+  std::vector<unsigned char> row((size_t)w * 3);
+  for(int y = 0; y < h; y++)
+  {
+    for(int x = 0; x < w; x++)
+      for(int c = 0; c < 3; c++)
+      {
+        float v = rgba[((size_t)y * w + x) * 4 + c];
+        v = std::pow(std::fmax(v, 0.0f), 1.0f / 2.2f);  // post.frag:39
+        row[(size_t)x * 3 + c] = (unsigned char)(std::fmin(v, 1.0f) * 255.0f + 0.5f);
+      }
+    f.write((const char*)row.data(), (std::streamsize)row.size());
+  }
+}
+
+void writePFM(const std::string& path, const std::vector<float>& rgba, int w, int h)
+{
+  std::ofstream f(path, std::ios::binary);
+  f << "PF\n" << w << " " << h << "\n-1.0\n";
+  std::vector<float> row((size_t)w * 3);
+  for(int y = h - 1; y >= 0; y--)  // PFM stores the bottom row first
+  {
+    for(int x = 0; x < w; x++)
+      for(int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = rgba[((size_t)y * w + x) * 4 + c];
+    f.write((const char*)row.data(), (std::streamsize)(row.size() * sizeof(float)));
+  }
+}
+
+}  // namespace vkrt_host

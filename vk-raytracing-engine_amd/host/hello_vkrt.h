@@ -1,0 +1,108 @@
+// hello_vkrt.h -- C++ host mirror of the reference renderer object for the ray-tracing path.
+//
+// Same member names, argument meaning and call order as the slice of `class HelloVulkan`
+// (reference hello_vulkan.h:56-208) that the path tracer uses, so a maintainer can swap the object
+// under main.cpp's init sequence (main.cpp:226-240) and frame loop (main.cpp:504-508):
+//
+//   reference                                         here
+//   loadGltfScene(filename)      hello_vulkan.cpp:327  loadGltfScene(filename)   -> vkrt_scene_create
+//   initRayTracing()             :901                  initRayTracing()          (defaults :911-918)
+//   createBottomLevelASGltf()    :1001                 createBottomLevelASGltf() -> vkrt_accel_build
+//   createTopLevelAsGltf()       :1031                 createTopLevelAsGltf()    (instances are part of the same build)
+//   createOffscreenRender()      :637                  createOffscreenRender()   (rgba32f image in HBM)
+//   updateUniformBuffer(cmdBuf)  :61                   updateUniformBuffer()
+//   updateFrame()/resetFrame()   :1501-1521            updateFrame()/resetFrame()
+//   pathtrace(cmdBuf,clearColor) :1423                 pathtrace(clearColor)     -> vkrt_pathtrace
+//   destroyResources()           :518                  destroyResources()
+//
+// Errors: the reference asserts / throws std::runtime_error (:336,:341,:1243); this class throws
+// std::runtime_error carrying vkrt_last_error().  Everything below the class is the C ABI (include/vkrt.h).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/vkrt.h"
+#include "camera.h"
+#include "gltf_scene.h"
+
+namespace vkrt_host {
+
+class HelloVkrt
+{
+public:
+  explicit HelloVkrt(int device = 0) : m_device(device) {}
+  ~HelloVkrt() { destroyResources(); }
+  HelloVkrt(const HelloVkrt&) = delete;
+  HelloVkrt& operator=(const HelloVkrt&) = delete;
+
+  void setup(int width, int height);                      // AppBaseVk::setup + window size
+  void loadGltfScene(const std::string& filename);        // hello_vulkan.cpp:327-394
+  void loadScene(const GltfScene& scene);                 // same upload from an in-memory scene
+  void initRayTracing();                                  // :901-919
+  void createBottomLevelASGltf();                         // :1001-1011
+  void createTopLevelAsGltf();                            // :1031-1047
+  void createOffscreenRender();                           // :637-665 (colour image only)
+  void updateUniformBuffer();                             // :61-102
+  void resetFrame();                                      // :1501-1504
+  void updateFrame();                                     // :1506-1521
+  void pathtrace(const float clearColor[4]);              // :1423-1448
+  void onResize(int w, int h);                            // :620-626
+  void destroyResources();                                // :518-578
+
+  // read back m_offscreenColor (rgba32f, row 0 = top) -- what drawPost samples (:882-897)
+  void downloadImage(std::vector<float>& rgba) const;
+  vkrt_counters counters();
+  vkrt_accel_info accelInfo() const;
+  float lastTraceMs();
+
+  // public state, as in the reference class
+  PushConstantRay m_pcRay{{1, 1, 1, 1}, -1, 0, 1, 3, 1, 1, 0};  // frame = -1 until the first updateFrame
+  int m_maxFrames{10};            // hello_vulkan.h:156
+  bool m_stopAtMaxFrames{false};  // hello_vulkan.h:157
+  CameraManipulator CameraManip;  // the nvh global of the reference
+  GlobalUniforms m_hostUBO{};
+  GltfScene m_gltfScene;
+  struct { int width = 1280, height = 720; } m_size;
+  uint32_t m_seed = 0;            // replaces int(clockARB()) (raytrace.rgen:27); advanced every frame
+  uint32_t m_buildFlags = VKRT_BUILD_DEFAULT;
+  uint32_t m_traceFlags = 0;
+
+private:
+  void check(int rc, const char* what) const;
+  int m_device;
+  vkrt_scene* m_scene = nullptr;
+  float* m_offscreenColor = nullptr;  // device rgba32f
+  bool m_blasRequested = false;
+  // updateFrame()'s function-local statics in the reference (:1508-1509)
+  vkrt_mat4 m_refCamMatrix{};
+  float m_refFov = 60.0f;
+  bool m_refValid = false;
+};
+
+// config.json of the reference (main.cpp:136-145): the five mandatory keys plus optional ones that
+// stand in for the ImGui panel (main.cpp:67-105,448-465).
+struct AppConfig
+{
+  std::vector<std::string> scenes;
+  int scene = 0;
+  bool vsync = false;
+  int width = 1280, height = 720;
+  // optional
+  int samples = 1, depth = 3, frames = 1, seed = 0;
+  bool seedPerFrame = true;
+  float clearColor[4] = {1, 1, 1, 1};  // main.cpp:247
+  bool hasCamera = false;
+  Vec3 eye{0, 0, 15}, center{0, 0, 0}, up{0, 1, 0};
+  float fov = 60.0f;
+  std::string build = "sah";
+  std::string output;
+  std::string scenePath() const { return scenes.at((size_t)scene); }
+};
+AppConfig parseConfig(const std::string& jsonText);
+AppConfig loadConfig(const std::string& path);
+
+// post.frag:39,58 -- gamma 1/2.2 on all four channels; writers for review images
+void writePPM(const std::string& path, const std::vector<float>& rgba, int w, int h);
+void writePFM(const std::string& path, const std::vector<float>& rgba, int w, int h);
+
+}  // namespace vkrt_host

@@ -1,0 +1,106 @@
+"""ctypes access to the C++ host layer (libvkrt_host.so) for the test harness."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import HOST_LIB_PATH, abi
+from .flat_scene import FlatScene, LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (same HIP-runtime load-order rule as renderer.load_library)
+
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} missing: run __graft_entry__.build()")
+        L = C.CDLL(HOST_LIB_PATH)
+        L.vkrt_host_last_error.restype = C.c_char_p
+        L.vkrt_host_load_gltf.argtypes = [C.c_char_p]
+        L.vkrt_host_load_gltf.restype = C.c_void_p
+        L.vkrt_host_free_scene.argtypes = [C.c_void_p]
+        L.vkrt_host_scene_counts.argtypes = [C.c_void_p, C.c_void_p]
+        L.vkrt_host_scene_copy.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+        L.vkrt_host_texture_info.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.vkrt_host_texture_copy.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.vkrt_host_global_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.POINTER(abi.GlobalUniforms)]
+        L.vkrt_host_parse_config.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
+        L.vkrt_host_parse_config.restype = C.c_int
+        L.vkrt_host_render_gltf.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p]
+        L.vkrt_host_render_gltf.restype = C.c_int
+        L.vkrt_host_decode_png.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.vkrt_host_decode_png.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def load_gltf(path):
+    """C++ loader -> FlatScene."""
+    L = lib()
+    h = L.vkrt_host_load_gltf(os.fsencode(path))
+    if not h:
+        raise RuntimeError("vkrt_host_load_gltf: " + L.vkrt_host_last_error().decode())
+    try:
+        cnt = np.zeros(7, np.uint32)
+        L.vkrt_host_scene_counts(h, cnt.ctypes.data)
+        V, I, P, N, M, Lc, T = (int(x) for x in cnt)
+        pos, nrm = np.zeros((V, 3), np.float32), np.zeros((V, 3), np.float32)
+        tan, uv = np.zeros((V, 4), np.float32), np.zeros((V, 2), np.float32)
+        idx = np.zeros(I, np.uint32)
+        pm, nd = np.zeros(P, PRIM_DTYPE), np.zeros(N, NODE_DTYPE)
+        mats, lights = np.zeros(M, MAT_DTYPE), np.zeros(Lc, LIGHT_DTYPE)
+        L.vkrt_host_scene_copy(h, *(a.ctypes.data for a in (pos, nrm, tan, uv, idx, pm, nd, mats, lights)))
+        tex = []
+        for i in range(T):
+            whs = np.zeros(3, np.uint32)
+            L.vkrt_host_texture_info(h, i, whs.ctypes.data)
+            px = np.zeros((int(whs[1]), int(whs[0]), 4), np.uint8)
+            L.vkrt_host_texture_copy(h, i, px.ctypes.data)
+            tex.append({"rgba8": px, "is_srgb": bool(whs[2])})
+        return FlatScene(pos, nrm, tan, uv, idx, pm, mats, lights, nd, tex)
+    finally:
+        L.vkrt_host_free_scene(h)
+
+
+def global_uniforms(eye=(0, 0, 15), center=(0, 0, 0), up=(0, 1, 0), fov=60.0, width=1280, height=720):
+    u = abi.GlobalUniforms()
+    e, c, p = (np.asarray(v, np.float32) for v in (eye, center, up))
+    lib().vkrt_host_global_uniforms(e.ctypes.data, c.ctypes.data, p.ctypes.data, fov, width, height, C.byref(u))
+    return u
+
+
+def parse_config(text):
+    out = np.zeros(9, np.int32)
+    path = C.create_string_buffer(1024)
+    rc = lib().vkrt_host_parse_config(text.encode(), out.ctypes.data, path, 1024)
+    if rc != 0:
+        raise ValueError(lib().vkrt_host_last_error().decode())
+    keys = ["scene", "vsync", "width", "height", "samples", "depth", "frames", "seed", "nscenes"]
+    d = dict(zip(keys, (int(x) for x in out)))
+    d["scene_path"] = path.value.decode()
+    return d
+
+
+def render_gltf(path, width, height, samples=1, depth=3, frames=1, seed0=0, eye=(0, 0, 15), center=(0, 0, 0), up=(0, 1, 0), fov=60.0,
+                build=abi.VKRT_BUILD_SAH_HOST, device=0):
+    img = np.zeros((height, width, 4), np.float32)
+    e, c, p = (np.asarray(v, np.float32) for v in (eye, center, up))
+    rc = lib().vkrt_host_render_gltf(os.fsencode(path), device, width, height, samples, depth, frames, seed0, e.ctypes.data,
+                                     c.ctypes.data, p.ctypes.data, fov, build, img.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("vkrt_host_render_gltf: " + lib().vkrt_host_last_error().decode())
+    return img
+
+
+def decode_png(data):
+    wh = np.zeros(2, np.uint32)
+    buf = np.frombuffer(data, np.uint8)
+    if lib().vkrt_host_decode_png(buf.ctypes.data, buf.size, wh.ctypes.data, None, 0) != 0:
+        raise ValueError(lib().vkrt_host_last_error().decode())
+    out = np.zeros((int(wh[1]), int(wh[0]), 4), np.uint8)
+    lib().vkrt_host_decode_png(buf.ctypes.data, buf.size, wh.ctypes.data, out.ctypes.data, out.size)
+    return out
