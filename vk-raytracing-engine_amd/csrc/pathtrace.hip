@@ -10,6 +10,7 @@
 // Pixels are handed out in 8x8 tiles so the 64 pixels a fresh wave pulls are one screen tile.
 // Per-lane traversal stacks live in LDS (entry k of lane l at stack[k*BLOCK + l]: bank-conflict free).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "device_math.h"
 #include "device_scene.h"
 #include "shade.h"
@@ -96,8 +97,8 @@ VKRT_DEV uint32_t globalRow(const TraceParams& P, uint32_t lrow)
   return (s * P.shardCount + P.shardIndex) * P.stripRows + r;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(VKRT_BLOCK) void k_pathtrace(const TraceParams P)
+template <bool COUNT, int MINW>
+__global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParams P)
 {
   extern __shared__ int lds_stack[];
   int* stk = lds_stack + threadIdx.x;
@@ -285,13 +286,32 @@ __global__ void k_eval_math(int op, unsigned n, const float* a, const float* b, 
 }
 
 // ---- launch wrappers (called from vkrt_api.cpp) ------------------------------------------------------
+// MINW = minimum waves per SIMD the register allocator must allow (occupancy knob; variant 0 = default)
+static int g_variant = -1;
+static int pathtraceVariant()
+{
+  if(g_variant < 0)
+  {
+    const char* e = getenv("VKRT_MINWAVES");
+    g_variant = e ? atoi(e) : 3;  // 3 waves/SIMD measured +34% over the unconstrained build (profiles/r01_v1_*)
+  }
+  return g_variant;
+}
+
 hipError_t vkrt_launch_pathtrace(const TraceParams& P, unsigned gridBlocks, bool count, hipStream_t stream)
 {
   const size_t lds = (size_t)P.sc.stackCap * VKRT_BLOCK * sizeof(int);
+  const dim3 g(gridBlocks), b(VKRT_BLOCK);
   if(count)
-    hipLaunchKernelGGL(k_pathtrace<true>, dim3(gridBlocks), dim3(VKRT_BLOCK), lds, stream, P);
+    hipLaunchKernelGGL((k_pathtrace<true, 1>), g, b, lds, stream, P);
   else
-    hipLaunchKernelGGL(k_pathtrace<false>, dim3(gridBlocks), dim3(VKRT_BLOCK), lds, stream, P);
+    switch(pathtraceVariant())
+    {
+      case 3: hipLaunchKernelGGL((k_pathtrace<false, 3>), g, b, lds, stream, P); break;
+      case 4: hipLaunchKernelGGL((k_pathtrace<false, 4>), g, b, lds, stream, P); break;
+      case 2: hipLaunchKernelGGL((k_pathtrace<false, 2>), g, b, lds, stream, P); break;
+      default: hipLaunchKernelGGL((k_pathtrace<false, 1>), g, b, lds, stream, P); break;
+    }
   return hipGetLastError();
 }
 
@@ -299,7 +319,13 @@ int vkrt_pathtrace_block_size() { return VKRT_BLOCK; }
 
 hipError_t vkrt_pathtrace_occupancy(size_t ldsBytes, int* blocksPerCU)
 {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false>, VKRT_BLOCK, ldsBytes);
+  switch(pathtraceVariant())
+  {
+    case 3: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 3>, VKRT_BLOCK, ldsBytes);
+    case 4: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 4>, VKRT_BLOCK, ldsBytes);
+    case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 2>, VKRT_BLOCK, ldsBytes);
+    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 1>, VKRT_BLOCK, ldsBytes);
+  }
 }
 
 hipError_t vkrt_launch_trace_rays(const DevScene& sc, unsigned n, const float* o, const float* d, float tmin, float tmax, int anyHit,
