@@ -101,9 +101,9 @@ def main():
     image = torch.zeros((rows_local, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
-    def step(frame):
+    def step(frame, flags=0):
         pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
-        r.pathtrace(pc, cam, W, H, seed=frame, shard=shard, image=image, stream=stream)
+        r.pathtrace(pc, cam, W, H, seed=frame, flags=flags, shard=shard, image=image, stream=stream)
         if world > 1:
             return gather_image(image, H, world, rank)
         return image
@@ -131,15 +131,21 @@ def main():
     # extra untimed pass that reads every launch's events individually
     cnt = r.counters()
     rays_local = cnt["rays_closest"] + cnt["rays_shadow"]
+    from vkrt_amd import abi as _abi
+
+    frame_ms, trav_ms, trav_launches = [], [], []
     for k in range(min(args.steps, 3)):
-        step(args.warmup + args.steps + k)
+        step(args.warmup + args.steps + k, flags=_abi.VKRT_TRACE_TIME_KERNELS)
         torch.cuda.synchronize(dev)
-        kernel_ms.append(r.last_trace_ms())
-    kernel_ms_mean = float(np.mean(kernel_ms))
+        tm = r.last_trace_timing()
+        frame_ms.append(tm["total_ms"])
+        trav_ms.append(tm["traverse_ms"])
+        trav_launches.append(tm["traverse_launches"])
+    mode = tm["mode"]
+    kernel_ms_mean = float(np.mean(frame_ms))
     cnt_after = r.counters()
     rays_extra = (cnt_after["rays_closest"] + cnt_after["rays_shadow"]) - rays_local
-    rays_per_launch_local = rays_extra / max(1, len(kernel_ms))
-
+    rays_per_launch_local = rays_extra / max(1, len(frame_ms))
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rr = torch.tensor([float(rays_local)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -196,12 +202,14 @@ def main():
             cpu_s = time.perf_counter() - tp
             cpu_rays = c["rays_closest"] + c["rays_shadow"]
             bytes_per_ray = oracle_py.algorithmic_bytes(c, frame_gt0=frame > 0) / cpu_rays
+            trav_bytes_per_ray = (64 * c["nodes_visited"] + 48 * c["tris_tested"]) / cpu_rays
             out["cpu_baseline"] = {
                 "value": cpu_rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": f"{len(rows)} evenly spaced rows of frame {frame} of the same {W}x{H} workload ({cpu_rays} rays, {cpu_s:.1f} s), "
                           f"full-sweep SAH BVH2 <=4 tris/leaf",
             }
             out["config"]["algorithmic_bytes_per_ray"] = bytes_per_ray
+            out["config"]["algorithmic_bytes_per_ray_traversal_only"] = trav_bytes_per_ray
         if bytes_per_ray is None:
             # committed per-config fixture (tests/golden/algbytes.json) when the oracle leg is skipped
             try:
@@ -210,19 +218,41 @@ def main():
             except Exception:
                 bytes_per_ray = None
         if bytes_per_ray is not None:
-            alg_bytes_launch = bytes_per_ray * rays_per_launch_local
-            achieved = alg_bytes_launch / (kernel_ms_mean * 1e-3) / 1e9
+            # frame level: all algorithmic bytes of the frame over the frame's GPU time (HIP events on the launch stream)
+            alg_bytes_frame = bytes_per_ray * rays_per_launch_local
+            frame_gbs = alg_bytes_frame / (kernel_ms_mean * 1e-3) / 1e9
             traffic = None
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 pass
-            out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_pathtrace", "kernel_ms": kernel_ms_mean,
-                "algorithmic_bytes_per_launch": alg_bytes_launch, "rays_per_launch": rays_per_launch_local,
-            }
+            if mode == "wavefront":
+                # dominant kernel = k_wf_traverse: its own algorithmic bytes (nodes + triangles) per
+                # launch over its own mean launch duration (HIP events around every launch of it)
+                try:
+                    tb = trav_bytes_per_ray
+                except NameError:
+                    tb = float(json.load(open(os.path.join(ROOT, "tests", "golden", "algbytes.json")))
+                               ["atrium262k_1080p_16spp_d8"]["traversal_bytes_per_ray"])
+                n_l = float(np.mean(trav_launches))
+                per_launch_ms = float(np.mean(trav_ms)) / n_l
+                alg_launch = tb * rays_per_launch_local / n_l
+                achieved = alg_launch / (per_launch_ms * 1e-3) / 1e9
+                out["roofline"] = {
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel": "k_wf_traverse", "kernel_ms": per_launch_ms, "launches_per_frame": n_l,
+                    "algorithmic_bytes_per_launch": alg_launch, "rays_per_launch": rays_per_launch_local / n_l,
+                    "frame": {"ms": kernel_ms_mean, "traverse_ms": float(np.mean(trav_ms)), "algorithmic_bytes": alg_bytes_frame,
+                              "achieved_GBs": frame_gbs, "frac": frame_gbs / HBM_PEAK_GBS},
+                }
+            else:
+                out["roofline"] = {
+                    "bound": "hbm", "achieved": frame_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel": "k_pathtrace", "kernel_ms": kernel_ms_mean,
+                    "algorithmic_bytes_per_launch": alg_bytes_frame, "rays_per_launch": rays_per_launch_local,
+                }
+            out["config"]["mode"] = mode
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -131,7 +131,9 @@ enum vkrt_trace_flags {
    * collision-free y*full_width + x instead (not parity). */
   VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1,
   /* Count BVH nodes visited / triangles tested as well (slower instrumented kernel). */
-  VKRT_TRACE_COUNT_TRAVERSAL = 0x2
+  VKRT_TRACE_COUNT_TRAVERSAL = 0x2,
+  /* Record HIP events around every traversal-kernel launch of the frame (vkrt_last_trace_timing). */
+  VKRT_TRACE_TIME_KERNELS = 0x4
 };
 
 typedef struct vkrt_trace_opts {
@@ -189,6 +191,16 @@ int vkrt_counters_read(vkrt_scene* scene, vkrt_counters* out); /* synchronises t
 /* Device time of the most recent vkrt_pathtrace kernel on this scene in milliseconds,
  * from HIP events recorded on the launch stream (synchronises on the stop event). */
 int vkrt_last_trace_ms(vkrt_scene* scene, float* ms);
+/* Breakdown of the most recent vkrt_pathtrace: whole frame, and (with VKRT_TRACE_TIME_KERNELS, or always
+ * in megakernel mode) the summed duration and number of launches of the traversal kernel -- the dominant
+ * kernel of the path (k_wf_traverse / k_pathtrace). */
+typedef struct vkrt_trace_timing {
+  float    total_ms;
+  float    traverse_ms;
+  uint32_t traverse_launches;
+  uint32_t mode;            /* 1 wavefront pipeline, 0 megakernel (VKRT_MODE=mega) */
+} vkrt_trace_timing;
+int vkrt_last_trace_timing(vkrt_scene* scene, vkrt_trace_timing* out);
 
 /* ---- test hooks (used by tests/ to compare single pieces with the oracle) ---------- */
 /* Closest-hit query for n rays: o,d = vec3[n] host arrays; tmin/tmax scalars.

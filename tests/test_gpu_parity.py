@@ -229,7 +229,7 @@ def test_traversal_counters_instrumented(renderers, cornell_oracle, cornell_flat
     _, cref = cornell_oracle.render(pc, cam, W, H, seed=0)
     assert c["rays_closest"] == cref["rays_closest"] and c["rays_shadow"] == cref["rays_shadow"]
     # different trees (binned vs full-sweep SAH), same order of magnitude of work per ray
-    assert 0.5 < c["nodes_visited"] / cref["nodes_visited"] < 2.0
+    assert 0.15 < c["nodes_visited"] / cref["nodes_visited"] < 2.0  # wide8 nodes cover ~3 binary levels
     assert 0.3 < c["tris_tested"] / cref["tris_tested"] < 3.0
 
 
@@ -291,3 +291,39 @@ def test_config3_full_size_rows_sample():
     r.close()
     assert rmse(img, ref) < RMSE_TOL
     assert mismatch_fraction(img, ref) < 1e-4
+
+
+def test_wavefront_and_megakernel_modes_agree(cornell_flat):
+    """The two schedulers of the same state machine (wavefront.hip default, pathtrace.hip via VKRT_MODE=mega)
+    must produce identical images; the megakernel runs in a child process because the mode is read once."""
+    import os, subprocess, sys, tempfile, textwrap
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    W, H = 200, 120
+    cam = default_camera(W, H)
+    pc = make_push_constants(samples=3, depth=4, frame=0, lights_count=1)
+    r = Renderer(cornell_flat, device=0, build="sah")
+    img = r.pathtrace(pc, cam, W, H, seed=13).cpu().numpy()
+    assert r.last_trace_timing()["mode"] == "wavefront"
+    r.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "mega.npy")
+        code = textwrap.dedent(f"""
+            import sys, numpy as np
+            sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); sys.path.insert(0, {os.path.join(root, 'oracle')!r})
+            import vkrt_amd
+            from vkrt_amd.flat_scene import FlatScene, make_push_constants
+            from vkrt_amd.renderer import Renderer
+            from conftest import default_camera
+            flat = FlatScene.load_npz({os.path.join(root, 'tests', 'golden', 'cornell_flat.npz')!r})
+            r = Renderer(flat, device=0, build="sah")
+            img = r.pathtrace(make_push_constants(samples=3, depth=4, frame=0, lights_count=1), default_camera({W}, {H}), {W}, {H}, seed=13).cpu().numpy()
+            assert r.last_trace_timing()["mode"] == "megakernel"
+            np.save({out!r}, img)
+        """)
+        env = dict(os.environ, VKRT_MODE="mega")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+        mega = np.load(out)
+    assert np.array_equal(img.view(np.uint32), mega.view(np.uint32))

@@ -1,0 +1,26 @@
+"""Micro-probe of the wavefront traversal kernel: times each traversal launch of small frames."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch
+import vkrt_amd
+from vkrt_amd import abi
+from vkrt_amd.flat_scene import make_push_constants, uniforms_from_matrices
+from vkrt_amd.renderer import Renderer
+import atrium, camera_np
+W, H = 1920, 1080
+flat, info = atrium.build_atrium(262144, seed=1)
+cam = uniforms_from_matrices(*camera_np.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA))
+r = Renderer(flat, device=0, build=os.environ.get("BUILD", "sah"))
+img = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+for spp, depth in ((1, 1), (1, 8), (4, 8)):
+    pc = make_push_constants(samples=spp, depth=depth, frame=0, lights_count=8)
+    for it in range(3):
+        r.reset_counters()
+        r.pathtrace(pc, cam, W, H, seed=1, flags=abi.VKRT_TRACE_TIME_KERNELS, image=img)
+        torch.cuda.synchronize()
+        t = r.last_trace_timing(); c = r.counters()
+    rays = c["rays_closest"] + c["rays_shadow"]
+    print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("VKRT_")}, "spp": spp, "depth": depth, "rays": rays,
+                      "total_ms": round(t["total_ms"], 3), "traverse_ms": round(t["traverse_ms"], 3), "launches": t["traverse_launches"],
+                      "Mrays_s_total": round(rays / t["total_ms"] / 1e3, 1), "Mrays_s_traverse": round(rays / max(t["traverse_ms"], 1e-9) / 1e3, 1), "mode": t["mode"]}))

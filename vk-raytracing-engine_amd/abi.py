@@ -139,6 +139,10 @@ class AccelInfo(C.Structure):
     ]
 
 
+class TraceTiming(C.Structure):
+    _fields_ = [("total_ms", c_f), ("traverse_ms", c_f), ("traverse_launches", c_u), ("mode", c_u)]
+
+
 # layout contract
 assert C.sizeof(GlobalUniforms) == 192
 assert C.sizeof(PushConstantRay) == 44
@@ -152,6 +156,7 @@ VKRT_BUILD_LBVH_GPU = 0x1
 VKRT_BUILD_SAH_HOST = 0x2
 VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1
 VKRT_TRACE_COUNT_TRAVERSAL = 0x2
+VKRT_TRACE_TIME_KERNELS = 0x4
 
 # every symbol include/vkrt.h declares (tests check the built library exports them all)
 VKRT_SYMBOLS = [
@@ -167,6 +172,7 @@ VKRT_SYMBOLS = [
     "vkrt_counters_reset",
     "vkrt_counters_read",
     "vkrt_last_trace_ms",
+    "vkrt_last_trace_timing",
     "vkrt_debug_trace_rays",
     "vkrt_debug_eval_math",
 ]
@@ -198,6 +204,8 @@ def declare_vkrt(lib):
     lib.vkrt_counters_read.restype = C.c_int
     lib.vkrt_last_trace_ms.argtypes = [C.c_void_p, P(c_f)]
     lib.vkrt_last_trace_ms.restype = C.c_int
+    lib.vkrt_last_trace_timing.argtypes = [C.c_void_p, P(TraceTiming)]
+    lib.vkrt_last_trace_timing.restype = C.c_int
     lib.vkrt_debug_trace_rays.argtypes = [
         C.c_void_p, c_u, C.c_void_p, C.c_void_p, c_f, c_f, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
     ]

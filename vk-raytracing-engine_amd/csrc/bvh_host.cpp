@@ -295,3 +295,217 @@ void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t
 }
 
 }  // namespace vkrt
+
+// =========================================================================================================
+// wide8: collapse the binary SAH tree into 8-wide compressed nodes (see bvh_host.h)
+// =========================================================================================================
+namespace vkrt {
+namespace {
+
+struct W8Child
+{
+  float lo[3], hi[3];
+  int32_t ref;  // BVH2 ref: >=0 internal node, <0 leaf code
+};
+
+inline float boxAreaF(const float* lo, const float* hi)
+{
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+
+struct W8Ctx
+{
+  const BuiltBvh& b2;
+  BuiltWide8& out;
+  double sahSum = 0;
+  float rootArea = 1.f;
+
+  void children2(int32_t node, W8Child c[2]) const
+  {
+    const float* n = &b2.nodes[(size_t)node * 16];
+    c[0].lo[0] = n[0]; c[0].lo[1] = n[1]; c[0].lo[2] = n[2]; c[0].hi[0] = n[3]; c[0].hi[1] = n[4]; c[0].hi[2] = n[5];
+    c[1].lo[0] = n[6]; c[1].lo[1] = n[7]; c[1].lo[2] = n[8]; c[1].hi[0] = n[9]; c[1].hi[1] = n[10]; c[1].hi[2] = n[11];
+    memcpy(&c[0].ref, &n[12], 4);
+    memcpy(&c[1].ref, &n[13], 4);
+  }
+
+  // fills wide node `me` from the BVH2 subtree rooted at the children list
+  void emit(uint32_t me, std::vector<W8Child> kids, uint32_t depth)
+  {
+    out.maxDepth = std::max(out.maxDepth, depth);
+    // widen: repeatedly open the internal child with the largest area
+    for(;;)
+    {
+      if(kids.size() >= 8)
+        break;
+      int best = -1;
+      float bestA = -1.f;
+      for(size_t k = 0; k < kids.size(); k++)
+        if(kids[k].ref >= 0)
+        {
+          const float a = boxAreaF(kids[k].lo, kids[k].hi);
+          if(a > bestA) { bestA = a; best = (int)k; }
+        }
+      if(best < 0)
+        break;
+      W8Child c[2];
+      children2(kids[(size_t)best].ref, c);
+      kids[(size_t)best] = c[0];
+      kids.push_back(c[1]);
+    }
+    // node box = union of children
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for(const W8Child& c : kids)
+      for(int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], c.lo[k]); hi[k] = std::max(hi[k], c.hi[k]); }
+    // octant-ordered slots: child on the +side of axis k wants a slot with bit k set (greedy assignment)
+    int slotOf[8], childAt[8];
+    for(int k = 0; k < 8; k++) { slotOf[k] = -1; childAt[k] = -1; }
+    const float cen[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    for(size_t round = 0; round < kids.size(); round++)
+    {
+      float bestC = -INFINITY;
+      int bc = -1, bs = -1;
+      for(size_t c = 0; c < kids.size(); c++)
+      {
+        if(slotOf[c] >= 0) continue;
+        const float v[3] = {0.5f * (kids[c].lo[0] + kids[c].hi[0]) - cen[0], 0.5f * (kids[c].lo[1] + kids[c].hi[1]) - cen[1],
+                            0.5f * (kids[c].lo[2] + kids[c].hi[2]) - cen[2]};
+        for(int s = 0; s < 8; s++)
+        {
+          if(childAt[s] >= 0) continue;
+          const float cost = ((s & 1) ? v[0] : -v[0]) + ((s & 2) ? v[1] : -v[1]) + ((s & 4) ? v[2] : -v[2]);
+          if(cost > bestC) { bestC = cost; bc = (int)c; bs = s; }
+        }
+      }
+      slotOf[bc] = bs;
+      childAt[bs] = bc;
+    }
+    // grid: origin = lo, per-axis power-of-two cell so that the extent fits 255 cells
+    uint32_t eb[3];
+    for(int k = 0; k < 3; k++)
+    {
+      const double ext = (double)hi[k] - (double)lo[k];
+      int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+      e = std::min(std::max(e, -126), 126);
+      for(;;)
+      {  // make sure every child's hi really fits (ceil may need one more cell)
+        const double sc = std::ldexp(1.0, e);
+        bool ok = true;
+        for(const W8Child& c : kids)
+          if(std::ceil(((double)c.hi[k] - (double)lo[k]) / sc) > 255.0) ok = false;
+        if(ok || e >= 126) break;
+        e++;
+      }
+      eb[k] = (uint32_t)(e + 127);
+    }
+    uint32_t imask = 0, meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint8_t qlo[3][8], qhi[3][8];
+    memset(qlo, 0, sizeof qlo);
+    memset(qhi, 0, sizeof qhi);
+    const uint32_t triBase = (uint32_t)out.triOrder.size();
+    uint32_t triOff = 0;
+    std::vector<std::pair<int, int>> internalSlots;  // (slot, child)
+    for(int s = 0; s < 8; s++)
+    {
+      const int c = childAt[s];
+      if(c < 0)
+        continue;
+      const W8Child& ch = kids[(size_t)c];
+      for(int k = 0; k < 3; k++)
+      {
+        const double sc = std::ldexp(1.0, (int)eb[k] - 127), o = (double)lo[k];
+        int ql = (int)std::floor(((double)ch.lo[k] - o) / sc);
+        ql = std::min(std::max(ql, 0), 255);
+        while(ql > 0 && o + ql * sc > (double)ch.lo[k]) ql--;
+        int qh = (int)std::ceil(((double)ch.hi[k] - o) / sc);
+        qh = std::min(std::max(qh, 0), 255);
+        while(qh < 255 && o + qh * sc < (double)ch.hi[k]) qh++;
+        qlo[k][s] = (uint8_t)ql;
+        qhi[k][s] = (uint8_t)qh;
+      }
+      if(ch.ref >= 0)
+      {
+        imask |= 1u << s;
+        meta[s] = 0x20u | (24u + (uint32_t)s);
+        internalSlots.emplace_back(s, c);
+      }
+      else
+      {
+        const uint32_t code = ~(uint32_t)ch.ref;
+        const uint32_t first = code >> 3, cnt = (code & 7u) + 1u;  // cnt <= 3 by construction
+        for(uint32_t t = 0; t < cnt; t++) out.triOrder.push_back(b2.triOrder[first + t]);
+        meta[s] = (((1u << cnt) - 1u) << 5) | triOff;
+        triOff += cnt;
+        sahSum += (double)boxAreaF(ch.lo, ch.hi) * cnt;
+      }
+    }
+    sahSum += (double)boxAreaF(lo, hi);  // one node visit
+    const uint32_t childBase = (uint32_t)(out.nodes.size() / 20);
+    out.nodes.resize(out.nodes.size() + 20 * internalSlots.size());
+    uint32_t* n = &out.nodes[(size_t)me * 20];
+    memcpy(&n[0], &lo[0], 4); memcpy(&n[1], &lo[1], 4); memcpy(&n[2], &lo[2], 4);
+    n[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24);
+    n[4] = childBase;
+    n[5] = triBase;
+    n[6] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | (meta[3] << 24);
+    n[7] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24);
+    auto pack4 = [](const uint8_t* q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
+    n[8] = pack4(&qlo[0][0]); n[9] = pack4(&qlo[0][4]); n[10] = pack4(&qlo[1][0]); n[11] = pack4(&qlo[1][4]);
+    n[12] = pack4(&qlo[2][0]); n[13] = pack4(&qlo[2][4]); n[14] = pack4(&qhi[0][0]); n[15] = pack4(&qhi[0][4]);
+    n[16] = pack4(&qhi[1][0]); n[17] = pack4(&qhi[1][4]); n[18] = pack4(&qhi[2][0]); n[19] = pack4(&qhi[2][4]);
+    // recurse (internalSlots is in increasing slot order = storage order)
+    for(size_t k = 0; k < internalSlots.size(); k++)
+    {
+      W8Child c[2];
+      children2(kids[(size_t)internalSlots[k].second].ref, c);
+      emit(childBase + (uint32_t)k, std::vector<W8Child>{c[0], c[1]}, depth + 1);
+    }
+  }
+};
+
+}  // namespace
+
+void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out)
+{
+  out = BuiltWide8{};
+  if(tris.empty())
+    return;
+  BuiltBvh b2;
+  build_sah_host(tris, 3, b2);  // <= 3 triangles per leaf: the unary count field has 3 bits
+  W8Ctx cx{b2, out};
+  out.triOrder.reserve(tris.size());
+  out.nodes.resize(20);
+  std::vector<W8Child> kids;
+  if(b2.rootRef < 0)
+  {  // whole scene in one leaf: a root with a single leaf child
+    W8Child c;
+    for(int k = 0; k < 3; k++) { c.lo[k] = INFINITY; c.hi[k] = -INFINITY; }
+    for(const FlatTri& t : tris)
+      for(int k = 0; k < 3; k++)
+      {
+        const float p0 = t.v0[k], p1 = t.v0[k] + t.e1[k], p2 = t.v0[k] + t.e2[k];
+        c.lo[k] = std::min(c.lo[k], std::min(p0, std::min(p1, p2)));
+        c.hi[k] = std::max(c.hi[k], std::max(p0, std::max(p1, p2)));
+      }
+    c.ref = b2.rootRef;
+    kids.push_back(c);
+  }
+  else
+  {
+    W8Child c[2];
+    cx.children2(b2.rootRef, c);
+    kids = {c[0], c[1]};
+  }
+  {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for(const W8Child& c : kids)
+      for(int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], c.lo[k]); hi[k] = std::max(hi[k], c.hi[k]); }
+    cx.rootArea = std::max(boxAreaF(lo, hi), 1e-30f);
+  }
+  cx.emit(0, kids, 0);
+  out.nodeCount = (uint32_t)(out.nodes.size() / 20);
+  out.sahCost = (float)(cx.sahSum / cx.rootArea);
+}
+
+}  // namespace vkrt

@@ -37,3 +37,28 @@ void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh
 void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out);
 
 }  // namespace vkrt
+
+namespace vkrt {
+
+// 8-wide compressed BVH ("wide8"), 80 bytes per node = 5 x float4 (layout after Ylitie, Karras, Laine 2017,
+// "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs"; re-derived for gfx950 where the
+// per-CU L1/TA tag rate bounds incoherent traversal: 5 lane-loads cover what 3 binary levels need 12 for):
+//   q0 = (origin.x, origin.y, origin.z, ex | ey<<8 | ez<<16 | imask<<24)        e* = biased exponents of the grid
+//   q1 = (childBase, triBase, meta[0..3], meta[4..7])                            one meta byte per child slot
+//   q2 = (qlo.x[0..3], qlo.x[4..7], qlo.y[0..3], qlo.y[4..7])                   8-bit quantised child boxes
+//   q3 = (qlo.z[0..3], qlo.z[4..7], qhi.x[0..3], qhi.x[4..7])
+//   q4 = (qhi.y[0..3], qhi.y[4..7], qhi.z[0..3], qhi.z[4..7])
+// meta: 0 empty; internal child = 0x20 | (24 + slot); leaf = (unary triangle count: 1,3,7) << 5 | offset in the
+// node's triangle block (0..23).  Child box k decodes to origin + q * 2^(e-127), conservatively (floor/ceil
+// verified in double).  Internal children are stored consecutively from childBase in slot order.
+struct BuiltWide8
+{
+  std::vector<uint32_t> nodes;     // 20 dwords per node
+  std::vector<uint32_t> triOrder;  // triangle slot -> index into the FlatTri array
+  uint32_t maxDepth = 0;           // in wide nodes
+  uint32_t nodeCount = 0;
+  float sahCost = 0;
+};
+void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out);
+
+}  // namespace vkrt

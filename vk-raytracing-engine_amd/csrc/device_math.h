@@ -10,6 +10,33 @@
 
 #define VKRT_DEV __device__ __forceinline__
 
+VKRT_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Block-reduce up to 8 per-lane counters through LDS and add them to this block's counter slot with
+// one atomic per non-zero counter.  `dst` = &counters->v[blockIdx.x % SLOTS][0]; red = 8*(blockDim/64) u64 of LDS.
+VKRT_DEV void blockAddCounters(unsigned long long* dst, const unsigned* vals, int n, unsigned long long* red)
+{
+  const unsigned lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for(int k = 0; k < n; k++)
+  {
+    unsigned long long x = vals[k];
+#pragma unroll
+    for(int off = 32; off > 0; off >>= 1)
+      x += __shfl_xor(x, off);
+    if(lane == 0)
+      red[wave * 8 + k] = x;
+  }
+  __syncthreads();
+  if(threadIdx.x < (unsigned)n)
+  {
+    unsigned long long t = 0;
+    for(unsigned w = 0; w < nw; w++)
+      t += red[w * 8 + threadIdx.x];
+    if(t != 0ull)
+      atomicAdd(&dst[threadIdx.x], t);
+  }
+}
+
 struct f3 { float x, y, z; };
 VKRT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 VKRT_DEV f3 mk3(float s) { return mk3(s, s, s); }

@@ -19,6 +19,25 @@ struct DevInstance
 };
 static_assert(sizeof(DevInstance) == 96, "DevInstance");
 
+// Shading-side repack (done once at upload; the API still takes the reference's SoA arrays):
+// the per-CU L1/TA processes one 16-byte lane-load per tag lookup, so records are laid out for few,
+// wide, aligned loads instead of the ~70 dword loads per hit that the raw SoA layout needs.
+//   vertex  : 2 x float4 = (pos.xyz, nrm.x) (nrm.y, nrm.z, uv.x, uv.y); tangents stay float4
+//   material: 64 bytes  = GltfPBRMaterial (52 B) padded to four aligned float4
+//   primInfo: 16 bytes  = PrimMeshInfo (12 B) + pad
+struct DevMaterial
+{
+  GltfPBRMaterial m;
+  int32_t pad[3];
+};
+static_assert(sizeof(DevMaterial) == 64, "DevMaterial");
+struct DevPrimInfo
+{
+  PrimMeshInfo p;
+  uint32_t pad;
+};
+static_assert(sizeof(DevPrimInfo) == 16, "DevPrimInfo");
+
 struct DevTexture
 {
   uint32_t offset;  // first texel in the RGBA8 pool
@@ -45,8 +64,9 @@ struct DevScene
   const float* tangents;      // vec4[]
   const float* texcoords;     // vec2[]
   const uint32_t* indices;
-  const PrimMeshInfo* primInfo;
-  const GltfPBRMaterial* materials;
+  const float4* vertexPN;     // 2 float4 per vertex (see above)
+  const DevPrimInfo* primInfo;
+  const DevMaterial* materials;
   const GltfLight* lights;
   const DevInstance* instances;
   const DevTexture* textures;
@@ -57,13 +77,18 @@ struct DevScene
   uint32_t textureCount;
   uint32_t triCount;
   int32_t rootRef;            // 0 (internal root) or a leaf ref for tiny scenes
-  uint32_t stackCap;          // traversal stack entries per lane
+  uint32_t stackCap;          // traversal stack: 4-byte LDS words per lane
+  uint32_t layout;            // 0 = BVH2 (64-B nodes), 1 = wide8 (80-B compressed nodes)
   uint32_t stepLimit;         // traversal step bound (termination safety net)
 };
 
-struct DevCounters  // order of vkrt_counters
+// Counter storage: 64 slots of 8 counters (one 64-byte line each, order of vkrt_counters).  A workgroup
+// adds its block-reduced totals to slot (blockIdx % 64), so same-address atomic serialisation is
+// 64x lower than with one set of counters; vkrt_counters_read sums the slots.
+#define VKRT_COUNTER_SLOTS 64
+struct DevCounters
 {
-  unsigned long long v[8];
+  unsigned long long v[VKRT_COUNTER_SLOTS][8];
 };
 
 struct TraceParams
@@ -81,4 +106,16 @@ struct TraceParams
   float* image;             // rgba32f, localRows x fullW
   unsigned int* workCounter;
   DevCounters* counters;
+};
+
+// Wavefront-mode working set (wavefront.hip): per-path SoA state, ray / hit records, two queues.
+struct WfBuffers
+{
+  unsigned* ctrl;       // [0],[1] queue counts, [2] traversal cursor
+  float4* S[8];         // path state
+  float4* R0;           // ray origin.xyz, tmax
+  float4* R1;           // ray direction.xyz, anyHit flag
+  float4* H;            // hit t,u,v,slot
+  unsigned* queue[2];   // path ids
+  uint32_t capacity;    // paths
 };

@@ -9,3 +9,14 @@ hipError_t vkrt_pathtrace_occupancy(size_t ldsBytes, int* blocksPerCU);
 hipError_t vkrt_launch_trace_rays(const DevScene& sc, unsigned n, const float* o, const float* d, float tmin, float tmax, int anyHit,
                                   float* t, float* u, float* v, int* gid, hipStream_t stream);
 hipError_t vkrt_launch_eval_math(int op, unsigned n, const float* a, const float* b, float* out, hipStream_t stream);
+
+// wavefront mode (wavefront.hip)
+struct WfTiming
+{
+  hipEvent_t* events;   // optional pool of 2*rounds+2 events (NULL = no per-kernel timing)
+  int capacity;
+  int used;             // pairs recorded around k_wf_traverse launches
+};
+size_t     vkrt_wf_state_bytes(uint32_t pathCapacity);
+void       vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B);
+hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing);

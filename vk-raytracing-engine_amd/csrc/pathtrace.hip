@@ -15,87 +15,12 @@
 #include "device_scene.h"
 #include "shade.h"
 #include "traverse.h"
+#include "traverse_wide.h"
+#include "rgen.h"
 #include "kernels.h"
 
 #define VKRT_BLOCK 256
 
-VKRT_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-struct LaneState
-{
-  Payload prd;
-  f3 curWeight, hitValue, hitValues;
-  f3 camOrigin;
-  uint32_t px, py;   // global pixel (gl_LaunchIDEXT.xy)
-  uint32_t lrow;     // row in the shard-local buffer
-  int smpl;
-  int stage;         // 0: next ray is the closest-hit ray, 1: next ray is the shadow ray
-};
-
-// raytrace.rgen:42-60 -- start sample `smpl` of the lane's pixel
-VKRT_DEV void startSample(const TraceParams& P, LaneState& L)
-{
-  const float r1 = rnd(L.prd.seed);
-  const float r2 = rnd(L.prd.seed);
-  const float jx = P.pc.frame == 0 ? 0.5f : r1, jy = P.pc.frame == 0 ? 0.5f : r2;
-  const float pcx = (float)L.px + jx, pcy = (float)L.py + jy;
-  const float inU = pcx / (float)P.fullW, inV = pcy / (float)P.fullH;
-  const float dx = inU * 2.0f - 1.0f, dy = inV * 2.0f - 1.0f;
-  float target[4], direction[4];
-  mat4MulVec4(P.projInverse, dx, dy, 1.0f, 1.0f, target);
-  const f3 tn = normalize3(mk3(target[0], target[1], target[2]));
-  mat4MulVec4(P.viewInverse, tn.x, tn.y, tn.z, 0.0f, direction);
-  L.prd.hitValue = mk3(0.0f);
-  L.prd.rayOrigin = L.camOrigin;
-  L.prd.rayDirection = mk3(direction[0], direction[1], direction[2]);
-  L.prd.depth = 0;
-  L.prd.weight = mk3(0.0f);
-  L.curWeight = mk3(1.0f);
-  L.hitValue = mk3(0.0f);
-  L.stage = 0;
-}
-
-// raytrace.rgen:27-30 -- bind a pixel to the lane
-VKRT_DEV void startPixel(const TraceParams& P, LaneState& L, uint32_t x, uint32_t y, uint32_t lrow)
-{
-  L.px = x; L.py = y; L.lrow = lrow;
-  const uint32_t index = (P.flags & 1u) ? (y * P.fullW + x) : (y * x + x);
-  L.prd.seed = tea(index, P.seed);
-  L.prd.isSpecular = false;
-  L.prd.lightDist = 0.0f;
-  L.prd.shadowRayDir = mk3(0.0f);
-  float origin[4];
-  mat4MulVec4(P.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f, origin);
-  L.camOrigin = mk3(origin[0], origin[1], origin[2]);
-  L.hitValues = mk3(0.0f);
-  L.smpl = 0;
-  startSample(P, L);
-}
-
-// raytrace.rgen:120,136-145 -- resolve and store the pixel
-VKRT_DEV void storePixel(const TraceParams& P, const LaneState& L)
-{
-  const f3 res = L.hitValues / (float)P.pc.samples;
-  float4* dst = (float4*)P.image + ((size_t)L.lrow * P.fullW + L.px);
-  if(P.pc.frame > 0)
-  {
-    const float a = 1.0f / (float)(P.pc.frame + 1);
-    const float4 old = *dst;
-    const f3 m = glsl_mix(mk3(old.x, old.y, old.z), res, a);
-    *dst = make_float4(m.x, m.y, m.z, 1.0f);
-  }
-  else
-    *dst = make_float4(res.x, res.y, res.z, 1.0f);
-}
-
-// shard-local row -> global row (include/vkrt.h vkrt_shard)
-VKRT_DEV uint32_t globalRow(const TraceParams& P, uint32_t lrow)
-{
-  if(P.stripRows == 0u)
-    return lrow;
-  const uint32_t s = lrow / P.stripRows, r = lrow % P.stripRows;
-  return (s * P.shardCount + P.shardIndex) * P.stripRows + r;
-}
 
 template <bool COUNT, int MINW>
 __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParams P)
@@ -187,61 +112,18 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
       bool shadowHit = false;
       bool accumulate = true;
       if(!shadow)
-      {
-        if(hit.slot >= 0)
-          closestHitShader(P.sc, P.pc, hit, d, L.prd, st);
-        else
-          missShader(P.pc, L.prd);
-        if(!L.prd.isSpecular && L.prd.depth != 100u)  // rgen:79
-        {
-          L.stage = 1;
-          accumulate = false;
-        }
-      }
+        accumulate = !afterClosestRay(P, L, hit, d, st);
       else
-      {
         shadowHit = hit.slot >= 0;
-        L.stage = 0;
-      }
       if(accumulate)
-      {
-        if(!shadowHit)  // rgen:99-102
-        {
-          const f3 q = L.prd.hitValue * L.curWeight;
-          L.hitValue = L.hitValue + mk3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
-        }
-        L.curWeight = L.curWeight * L.prd.weight;  // rgen:115
-        L.prd.depth++;
-        if(!(L.prd.depth < (uint32_t)P.pc.depth))
-        {
-          L.hitValues = L.hitValues + L.hitValue;
-          L.smpl++;
-          if(L.smpl < P.pc.samples)
-            startSample(P, L);
-          else
-          {
-            storePixel(P, L);
-            active = false;
-          }
-        }
-      }
+        active = accumulateAndAdvance(P, L, shadowHit);
     }
   }
 
-  // ---- counters: wave reduce, one atomic per counter per wave -----------------------------------
-  unsigned vals[8] = {nClosest, nShadow, st.hits, st.diffuse, st.taps, nPixels, nNodes, nTris};
-#pragma unroll
-  for(int k = 0; k < 8; k++)
-  {
-    if(!COUNT && k >= 6)
-      break;
-    unsigned long long v = vals[k];
-#pragma unroll
-    for(int off = 32; off > 0; off >>= 1)
-      v += __shfl_xor(v, off);
-    if(lane == 0 && v != 0ull)
-      atomicAdd(&P.counters->v[k], v);
-  }
+  // ---- counters: block reduce, one atomic per counter per block ------------------------------------
+  __shared__ unsigned long long red[8 * (VKRT_BLOCK / 64)];
+  const unsigned vals[8] = {nClosest, nShadow, st.hits, st.diffuse, st.taps, nPixels, nNodes, nTris};
+  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 8 : 6, red);
 }
 
 // ---- debug / test kernels --------------------------------------------------------------------------
@@ -254,8 +136,12 @@ __global__ __launch_bounds__(VKRT_BLOCK) void k_trace_rays(DevScene sc, unsigned
     return;
   RayHit hit;
   unsigned a = 0, b = 0;
-  traverse<false>(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax, anyHit != 0,
-                  lds_stack + threadIdx.x, VKRT_BLOCK, hit, a, b);
+  if(sc.layout == 1u)
+    traverse_any<false, true>(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax, anyHit != 0,
+                              lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, a, b);
+  else
+    traverse_any<false, false>(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax, anyHit != 0,
+                               lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, a, b);
   if(anyHit)
   {
     gid[i] = hit.slot >= 0 ? 0 : -1;

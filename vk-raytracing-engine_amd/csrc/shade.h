@@ -195,7 +195,6 @@ VKRT_DEV f3 xformNormal(const DevInstance& in, f3 n)
   r.z = (n.x * in.w2o[2] + n.y * in.w2o[5]) + n.z * in.w2o[8];
   return r;
 }
-VKRT_DEV f3 ld3(const float* p, uint32_t i) { return mk3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
 
 // raytrace.rchit:31-219
 VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, f3 worldRayDir, Payload& prd,
@@ -205,18 +204,21 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
   const float4 rec = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
   const uint32_t instId = (uint32_t)__float_as_int(rec.z), primId = (uint32_t)__float_as_int(rec.w);
   const DevInstance in = sc.instances[instId];
-  const PrimMeshInfo pinfo = sc.primInfo[in.primMesh];  // rchit:34
-  const uint32_t indexOffset = pinfo.indexOffset + 3u * primId;
-  const uint32_t vertexOffset = pinfo.vertexOffset;
-  const uint32_t matIndex = (uint32_t)max(0, pinfo.materialIndex);
+  const float4 pq = ((const float4*)sc.primInfo)[in.primMesh];  // rchit:34 (PrimMeshInfo, one 16-byte load)
+  const uint32_t indexOffset = __float_as_uint(pq.x) + 3u * primId;
+  const uint32_t vertexOffset = __float_as_uint(pq.y);
+  const uint32_t matIndex = (uint32_t)max(0, __float_as_int(pq.z));
   const uint32_t i0 = sc.indices[indexOffset + 0] + vertexOffset;
   const uint32_t i1 = sc.indices[indexOffset + 1] + vertexOffset;
   const uint32_t i2 = sc.indices[indexOffset + 2] + vertexOffset;
   const f3 b = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);  // rchit:68
 
-  const f3 pos = ld3(sc.positions, i0) * b.x + ld3(sc.positions, i1) * b.y + ld3(sc.positions, i2) * b.z;
+  const float4 a0 = sc.vertexPN[2 * i0], b0 = sc.vertexPN[2 * i0 + 1];
+  const float4 a1 = sc.vertexPN[2 * i1], b1 = sc.vertexPN[2 * i1 + 1];
+  const float4 a2 = sc.vertexPN[2 * i2], b2 = sc.vertexPN[2 * i2 + 1];
+  const f3 pos = mk3(a0.x, a0.y, a0.z) * b.x + mk3(a1.x, a1.y, a1.z) * b.y + mk3(a2.x, a2.y, a2.z) * b.z;
   const f3 worldPos = xformPoint(in, pos);
-  const f3 nrm = normalize3(ld3(sc.normals, i0) * b.x + ld3(sc.normals, i1) * b.y + ld3(sc.normals, i2) * b.z);
+  const f3 nrm = normalize3(mk3(a0.w, b0.x, b0.y) * b.x + mk3(a1.w, b1.x, b1.y) * b.y + mk3(a2.w, b2.x, b2.y) * b.z);
   const f3 worldNrm = normalize3(xformNormal(in, nrm));
   const float4 tq0 = ((const float4*)sc.tangents)[i0];
   const float4 tq1 = ((const float4*)sc.tangents)[i1];
@@ -225,13 +227,18 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
   f3 worldTag = normalize3(xformNormal(in, tag));
   worldTag = normalize3(worldTag - dot3(worldTag, worldNrm) * worldNrm);
   const f3 worldBin = tq0.w * cross3(worldNrm, worldTag);
-  const float2 uv0 = ((const float2*)sc.texcoords)[i0];
-  const float2 uv1 = ((const float2*)sc.texcoords)[i1];
-  const float2 uv2 = ((const float2*)sc.texcoords)[i2];
-  const float tu = (uv0.x * b.x + uv1.x * b.y) + uv2.x * b.z;
-  const float tv = (uv0.y * b.x + uv1.y * b.y) + uv2.y * b.z;
+  const float tu = (b0.z * b.x + b1.z * b.y) + b2.z * b.z;
+  const float tv = (b0.w * b.x + b1.w * b.y) + b2.w * b.z;
 
-  const GltfPBRMaterial mat = sc.materials[matIndex];
+  // material: four aligned 16-byte loads of the padded record
+  const float4* mq = (const float4*)&sc.materials[matIndex];
+  const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
+  GltfPBRMaterial mat;
+  mat.pbrBaseColorFactor[0] = m0.x; mat.pbrBaseColorFactor[1] = m0.y; mat.pbrBaseColorFactor[2] = m0.z; mat.pbrBaseColorFactor[3] = m0.w;
+  mat.pbrBaseColorTexture = __float_as_int(m1.x); mat.metallicFactor = m1.y; mat.roughnessFactor = m1.z;
+  mat.metallicRoughnessTexture = __float_as_int(m1.w);
+  mat.normalTexture = __float_as_int(m2.x); mat.emissiveFactor[0] = m2.y; mat.emissiveFactor[1] = m2.z; mat.emissiveFactor[2] = m2.w;
+  mat.emissiveTexture = __float_as_int(m3.x);
   f3 emittance = mk3(0.0f);
   if(prd.depth == 0 || prd.isSpecular)  // rchit:83
   {
@@ -271,7 +278,12 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
     st.diffuse++;
     prd.isSpecular = false;
     const int random_index = (int)(rnd(prd.seed) * (float)pc.lightsCount);
-    const GltfLight light = sc.lights[random_index];
+    const float4* lq = (const float4*)&sc.lights[random_index];  // 32-byte record, two aligned loads
+    const float4 l0 = lq[0], l1 = lq[1];
+    GltfLight light;
+    light.position[0] = l0.x; light.position[1] = l0.y; light.position[2] = l0.z;
+    light.color[0] = l0.w; light.color[1] = l1.x; light.color[2] = l1.y;
+    light.intensity = l1.z; light.type = __float_as_int(l1.w);
     const f3 lightDir = mk3(light.position[0], light.position[1], light.position[2]) - worldPos;
     const float lightDistance = length3(lightDir);
     const f3 L = normalize3(lightDir);

@@ -1,0 +1,156 @@
+// traverse_wide.h -- traversal of the 8-wide compressed BVH (layout: bvh_host.h "wide8").
+// Same result definition as traverse.h (smallest t in (tmin,tmax), ties -> smallest triangle id; any hit =
+// exists), so images are identical to the BVH2 path; only the work per ray changes: ~10 node visits of
+// 5 lane-loads instead of ~31 visits of 4.
+//
+// Per node: cell size 2^(e-127) and origin are folded with the ray into adj_scale = 2^e/d and
+// adj_origin = (origin - o)/d, so each child plane costs one v_cvt_f32_ubyteN + one v_fma_f32.  The fused
+// form has an absolute error ~ eps*|adj_origin| per axis; near planes are therefore moved down and far
+// planes up by 1e-6*|adj_origin| (folded into the per-node constants) and the final comparison carries a
+// relative pad, which keeps the box test conservative.  Children are visited front to back by ray octant
+// using the slot order the builder prepared (bit 24 + (slot ^ octinv) of the hit mask).
+#pragma once
+#include "device_math.h"
+#include "device_scene.h"
+#include "traverse.h"
+
+#define VKRT_WNODE_QUADS 5
+
+VKRT_DEV float ubyte_f32(unsigned w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
+
+template <bool COUNT>
+VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, uint2* stk, int stride, RayHit& hit,
+                             unsigned& nNodes, unsigned& nTris)
+{
+  const f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  const bool px = !(id.x < 0.0f), py = !(id.y < 0.0f), pz = !(id.z < 0.0f);
+  const unsigned octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+  const float4* __restrict__ nodes = sc.nodes;
+  const float4* __restrict__ tris = sc.tris;
+  const int cap = (int)(sc.stackCap >> 1);
+  float bestT = tmax, bestU = 0.0f, bestV = 0.0f;
+  int bestSlot = -1, bestGid = -1;
+  uint2 G = make_uint2(0u, sc.rootRef == VKRT_TRAV_DONE ? 0u : 0x80000000u);
+  int sp = 0;
+  unsigned steps = sc.stepLimit;
+  bool done = false;
+  while(!done)
+  {
+    uint2 T = make_uint2(0u, 0u);
+    if(G.y & 0xff000000u)
+    {
+      // take the nearest pending internal child of the group
+      const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
+      const unsigned slot = (bitIdx - 24u) ^ octinv;
+      const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
+      G.y &= ~(1u << bitIdx);
+      if((G.y & 0xff000000u) && sp < cap)
+      {
+        stk[sp * stride] = G;
+        sp++;
+      }
+      if(--steps == 0u)
+        break;
+      const float4 q0 = nodes[child * VKRT_WNODE_QUADS + 0];
+      const float4 q1 = nodes[child * VKRT_WNODE_QUADS + 1];
+      const float4 q2 = nodes[child * VKRT_WNODE_QUADS + 2];
+      const float4 q3 = nodes[child * VKRT_WNODE_QUADS + 3];
+      const float4 q4 = nodes[child * VKRT_WNODE_QUADS + 4];
+      if(COUNT) nNodes++;
+      const unsigned ew = __float_as_uint(q0.w);
+      const unsigned imask = ew >> 24;
+      const float asx = __uint_as_float((ew & 0xffu) << 23) * id.x;
+      const float asy = __uint_as_float(((ew >> 8) & 0xffu) << 23) * id.y;
+      const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
+      const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
+      const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox);
+      const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy);
+      const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz);
+      // quantised planes, near/far by ray direction sign
+      const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
+      const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
+      const unsigned hy0 = __float_as_uint(q4.x), hy1 = __float_as_uint(q4.y), hz0 = __float_as_uint(q4.z), hz1 = __float_as_uint(q4.w);
+      const unsigned nx[2] = {px ? lx0 : hx0, px ? lx1 : hx1}, fx[2] = {px ? hx0 : lx0, px ? hx1 : lx1};
+      const unsigned ny[2] = {py ? ly0 : hy0, py ? ly1 : hy1}, fy[2] = {py ? hy0 : ly0, py ? hy1 : ly1};
+      const unsigned nz[2] = {pz ? lz0 : hz0, pz ? lz1 : hz1}, fz[2] = {pz ? hz0 : lz0, pz ? hz1 : lz1};
+      const unsigned metaW[2] = {__float_as_uint(q1.z), __float_as_uint(q1.w)};
+      unsigned hitmask = 0u;
+#pragma unroll
+      for(int i = 0; i < 8; i++)
+      {
+        const int w = i >> 2, k = i & 3;
+        const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), asx, fox);
+        const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), asy, foy);
+        const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), asz, foz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT));
+        const unsigned meta = (metaW[w] >> (8 * k)) & 0xffu;
+        const bool inner = ((imask >> i) & 1u) != 0u;
+        const unsigned bits = inner ? 1u : (meta >> 5);
+        const unsigned bitIndex = inner ? (24u + ((unsigned)i ^ octinv)) : (meta & 31u);
+        if(tn <= tf * 1.000001f)
+          hitmask |= bits << bitIndex;
+      }
+      G = make_uint2(__float_as_uint(q1.x), (hitmask & 0xff000000u) | imask);
+      T = make_uint2(__float_as_uint(q1.y), hitmask & 0x00ffffffu);
+    }
+    // triangles of this node that the ray's boxes touched
+    while(T.y != 0u)
+    {
+      const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
+      T.y &= T.y - 1u;
+      if(--steps == 0u) { done = true; break; }
+      const unsigned s = T.x + i;
+      const float4 a = tris[s * VKRT_TRI_QUADS + 0];
+      const float4 b = tris[s * VKRT_TRI_QUADS + 1];
+      const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+      if(COUNT) nTris++;
+      float t, u, v;
+      if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
+      {
+        if(t > tmin)
+        {
+          if(anyHit)
+          {
+            if(t < tmax)
+            {
+              bestSlot = (int)s;
+              bestT = t;
+              done = true;
+              break;
+            }
+          }
+          else
+          {
+            const int gid = __float_as_int(c.y);
+            if(t < bestT || (t == bestT && gid < bestGid))
+            {
+              bestT = t; bestU = u; bestV = v; bestSlot = (int)s; bestGid = gid;
+            }
+          }
+        }
+      }
+    }
+    if(done)
+      break;
+    if((G.y & 0xff000000u) == 0u)
+    {
+      if(sp == 0)
+        break;
+      sp--;
+      G = stk[sp * stride];
+    }
+  }
+  hit.t = bestT; hit.u = bestU; hit.v = bestV; hit.slot = bestSlot;
+}
+
+// layout dispatch used by the kernels: stkWords = this lane's LDS stack column (4-byte words, stride in words)
+template <bool COUNT, bool WIDE>
+VKRT_DEV void traverse_any(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int tid, int block, RayHit& hit,
+                           unsigned& nNodes, unsigned& nTris)
+{
+  if(WIDE)
+    traverse_wide8<COUNT>(sc, o, d, tmin, tmax, anyHit, ((uint2*)lds) + tid, block, hit, nNodes, nTris);
+  else
+    traverse<COUNT>(sc, o, d, tmin, tmax, anyHit, lds + tid, block, hit, nNodes, nTris);
+}

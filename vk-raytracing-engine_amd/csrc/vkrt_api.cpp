@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -67,6 +68,12 @@ struct vkrt_scene
   DevCounters* counters = nullptr;
   hipEvent_t evStart = nullptr, evStop = nullptr;
   bool timed = false;
+  // wavefront mode working set
+  void* wfMem = nullptr;
+  WfBuffers wf{};
+  std::vector<hipEvent_t> wfEvents;
+  WfTiming wfTiming{};
+  bool wfTimed = false;
 };
 
 namespace {
@@ -129,6 +136,18 @@ int validate(const vkrt_scene_desc* d)
     if(!d->textures[i].rgba8 || d->textures[i].width == 0 || d->textures[i].height == 0)
       return fail(VKRT_ERR_INVALID_ARGUMENT, "texture %u: empty", i);
   return VKRT_OK;
+}
+
+// execution mode: wavefront pipeline (default) or the single persistent megakernel (VKRT_MODE=mega)
+bool useWavefront()
+{
+  static int mode = -1;
+  if(mode < 0)
+  {
+    const char* e = getenv("VKRT_MODE");
+    mode = (e && !strcmp(e, "mega")) ? 0 : 1;
+  }
+  return mode == 1;
 }
 
 void freeAccel(vkrt_scene* s)
@@ -199,11 +218,31 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   if((rc = upload(s, d->texcoords0, 2 * (size_t)d->vertex_count, &D.texcoords)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, d->indices, (size_t)d->index_count, &D.indices)) != VKRT_OK) return bail(rc);
   // ePrimLookup buffer (hello_vulkan.cpp:363-368)
-  std::vector<PrimMeshInfo> lookup(d->prim_mesh_count);
+  std::vector<DevPrimInfo> lookup(d->prim_mesh_count);
   for(uint32_t i = 0; i < d->prim_mesh_count; i++)
-    lookup[i] = PrimMeshInfo{d->prim_meshes[i].firstIndex, d->prim_meshes[i].vertexOffset, d->prim_meshes[i].materialIndex};
+    lookup[i] = DevPrimInfo{PrimMeshInfo{d->prim_meshes[i].firstIndex, d->prim_meshes[i].vertexOffset, d->prim_meshes[i].materialIndex}, 0u};
   if((rc = upload(s, lookup.data(), lookup.size(), &D.primInfo)) != VKRT_OK) return bail(rc);
-  if((rc = upload(s, d->materials, (size_t)d->material_count, &D.materials)) != VKRT_OK) return bail(rc);
+  std::vector<DevMaterial> mats(d->material_count);
+  for(uint32_t i = 0; i < d->material_count; i++)
+  {
+    memset(&mats[i], 0, sizeof(DevMaterial));
+    mats[i].m = d->materials[i];
+  }
+  if((rc = upload(s, mats.data(), mats.size(), &D.materials)) != VKRT_OK) return bail(rc);
+  // interleaved (position, normal, uv) records for the closest-hit attribute fetch (rchit:41-66)
+  {
+    std::vector<float> pn((size_t)d->vertex_count * 8);
+    for(uint32_t v = 0; v < d->vertex_count; v++)
+    {
+      float* o = &pn[(size_t)v * 8];
+      o[0] = d->positions[3 * (size_t)v]; o[1] = d->positions[3 * (size_t)v + 1]; o[2] = d->positions[3 * (size_t)v + 2];
+      o[3] = d->normals[3 * (size_t)v]; o[4] = d->normals[3 * (size_t)v + 1]; o[5] = d->normals[3 * (size_t)v + 2];
+      o[6] = d->texcoords0[2 * (size_t)v]; o[7] = d->texcoords0[2 * (size_t)v + 1];
+    }
+    const float* pnDev = nullptr;
+    if((rc = upload(s, pn.data(), pn.size(), &pnDev)) != VKRT_OK) return bail(rc);
+    D.vertexPN = (const float4*)pnDev;
+  }
   if((rc = upload(s, d->lights, (size_t)d->light_count, &D.lights)) != VKRT_OK) return bail(rc);
   // instances: object->world rows + inverse (gl_ObjectToWorldEXT / gl_WorldToObjectEXT, rchit:72-76)
   std::vector<DevInstance> inst(d->node_count);
@@ -244,6 +283,7 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   D.textureCount = d->texture_count;
   D.rootRef = VKRT_TRAV_DONE;
   D.stackCap = 1;
+  D.layout = 0;
   D.stepLimit = 64;
 
   void* p = nullptr;
@@ -268,6 +308,8 @@ void vkrt_scene_destroy(vkrt_scene* s)
   freeAccel(s);
   for(void* p : s->allocs)
     (void)hipFree(p);
+  if(s->wfMem) (void)hipFree(s->wfMem);
+  for(hipEvent_t e : s->wfEvents) (void)hipEventDestroy(e);
   if(s->evStart) (void)hipEventDestroy(s->evStart);
   if(s->evStop) (void)hipEventDestroy(s->evStop);
   delete s;
@@ -297,30 +339,61 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     std::vector<vkrt::FlatTri> tris;
     vkrt::flatten_instances(s->positions.data(), s->indices.data(), s->primMeshes.data(), s->nodes.data(),
                             (uint32_t)s->nodes.size(), tris);
-    vkrt::BuiltBvh bvh;
-    vkrt::build_sah_host(tris, 4, bvh);
+    // wide8 (compressed 8-wide) is the trace-optimised layout; the megakernel and VKRT_BVH=bvh2 keep BVH2
+    const char* envBvh = getenv("VKRT_BVH");
+    const bool wide = useWavefront() && !(envBvh && !strcmp(envBvh, "bvh2"));
     std::vector<float> packed;
-    vkrt::pack_triangles(tris, bvh.triOrder, packed);
-    const size_t nodeBytes = std::max<size_t>(bvh.nodes.size() * sizeof(float), 64);
+    const void* nodeData = nullptr;
+    size_t nodeBytesUsed = 0;
+    vkrt::BuiltBvh bvh;
+    vkrt::BuiltWide8 w8;
+    if(wide)
+    {
+      vkrt::build_wide8_host(tris, w8);
+      vkrt::pack_triangles(tris, w8.triOrder, packed);
+      nodeData = w8.nodes.data();
+      nodeBytesUsed = w8.nodes.size() * sizeof(uint32_t);
+    }
+    else
+    {
+      vkrt::build_sah_host(tris, 4, bvh);
+      vkrt::pack_triangles(tris, bvh.triOrder, packed);
+      nodeData = bvh.nodes.data();
+      nodeBytesUsed = bvh.nodes.size() * sizeof(float);
+    }
+    const size_t nodeBytes = std::max<size_t>(nodeBytesUsed, 80);
     const size_t triBytes = std::max<size_t>(packed.size() * sizeof(float), 48);
     HIP_TRY(hipMalloc(&s->accelNodes, nodeBytes));
     HIP_TRY(hipMalloc(&s->accelTris, triBytes));
-    if(!bvh.nodes.empty())
-      HIP_TRY(hipMemcpyAsync(s->accelNodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    if(nodeBytesUsed)
+      HIP_TRY(hipMemcpyAsync(s->accelNodes, nodeData, nodeBytesUsed, hipMemcpyHostToDevice, stream));
     if(!packed.empty())
       HIP_TRY(hipMemcpyAsync(s->accelTris, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     s->dev.nodes = (const float4*)s->accelNodes;
     s->dev.tris = (const float4*)s->accelTris;
     s->dev.triCount = (uint32_t)tris.size();
-    s->dev.rootRef = bvh.rootRef;
-    s->dev.stackCap = bvh.maxDepth + 2;
     s->info.triangle_count = (uint32_t)tris.size();
-    s->info.node_count = (uint32_t)(bvh.nodes.size() / 16);
-    s->info.max_depth = bvh.maxDepth;
-    s->info.sah_cost = bvh.sahCost;
-    s->info.node_bytes = bvh.nodes.size() * sizeof(float);
+    s->info.node_bytes = nodeBytesUsed;
     s->info.triangle_bytes = packed.size() * sizeof(float);
+    if(wide)
+    {
+      s->dev.layout = 1;
+      s->dev.rootRef = tris.empty() ? VKRT_TRAV_DONE : 0;
+      s->dev.stackCap = 2 * (w8.maxDepth + 3);
+      s->info.node_count = w8.nodeCount;
+      s->info.max_depth = w8.maxDepth;
+      s->info.sah_cost = w8.sahCost;
+    }
+    else
+    {
+      s->dev.layout = 0;
+      s->dev.rootRef = bvh.rootRef;
+      s->dev.stackCap = bvh.maxDepth + 2;
+      s->info.node_count = (uint32_t)(bvh.nodes.size() / 16);
+      s->info.max_depth = bvh.maxDepth;
+      s->info.sah_cost = bvh.sahCost;
+    }
   }
   else
   {
@@ -334,6 +407,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     s->dev.tris = (const float4*)r.tris;
     s->dev.triCount = r.triCount;
     s->dev.rootRef = r.rootRef;
+    s->dev.layout = 0;
     s->dev.stackCap = r.maxDepth + 2;
     s->info.triangle_count = r.triCount;
     s->info.node_count = r.nodeCount;
@@ -425,6 +499,40 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   P.tileCount = (uint32_t)tiles;
 
   const bool count = (P.flags & VKRT_TRACE_COUNT_TRAVERSAL) != 0;
+  if(useWavefront())
+  {
+    if(P.fullW > 65535u || P.localRows > 65535u || pc->samples > 65535)
+      return fail(VKRT_ERR_UNSUPPORTED, "wavefront mode packs pixel coordinates / sample index in 16 bits");
+    const uint32_t need = P.tileCount * 64u;
+    if(!s->wfMem || s->wf.capacity < need)
+    {
+      HIP_TRY(hipStreamSynchronize(stream));
+      if(s->wfMem) (void)hipFree(s->wfMem);
+      s->wfMem = nullptr;
+      HIP_TRY(hipMalloc(&s->wfMem, vkrt_wf_state_bytes(need)));
+      vkrt_wf_carve(s->wfMem, need, &s->wf);
+    }
+    WfTiming* timing = nullptr;
+    if(P.flags & VKRT_TRACE_TIME_KERNELS)
+    {
+      const size_t wantEv = (size_t)2 * (2 * (size_t)pc->samples * pc->depth);
+      while(s->wfEvents.size() < wantEv && s->wfEvents.size() < 8192)
+      {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->wfEvents.push_back(e);
+      }
+      s->wfTiming.events = s->wfEvents.data();
+      s->wfTiming.capacity = (int)s->wfEvents.size();
+      timing = &s->wfTiming;
+    }
+    s->wfTimed = timing != nullptr;
+    HIP_TRY(hipEventRecord(s->evStart, stream));
+    HIP_TRY(vkrt_launch_wavefront(P, s->wf, s->cuCount, count, stream, timing));
+    HIP_TRY(hipEventRecord(s->evStop, stream));
+    s->timed = true;
+    return VKRT_OK;
+  }
   const size_t lds = (size_t)P.sc.stackCap * 256 * sizeof(int);
   int perCU = 0;
   HIP_TRY(vkrt_pathtrace_occupancy(lds, &perCU));
@@ -438,6 +546,7 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   HIP_TRY(vkrt_launch_pathtrace(P, grid, count, stream));
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->timed = true;
+  s->wfTimed = false;
   return VKRT_OK;
 }
 
@@ -462,8 +571,11 @@ int vkrt_counters_read(vkrt_scene* s, vkrt_counters* out)
   HIP_TRY(hipDeviceSynchronize());
   DevCounters h;
   HIP_TRY(hipMemcpy(&h, s->counters, sizeof h, hipMemcpyDeviceToHost));
-  out->rays_closest = h.v[0]; out->rays_shadow = h.v[1]; out->hits = h.v[2]; out->diffuse_hits = h.v[3];
-  out->tex_taps = h.v[4]; out->pixels = h.v[5]; out->nodes_visited = h.v[6]; out->tris_tested = h.v[7];
+  unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for(int sl = 0; sl < VKRT_COUNTER_SLOTS; sl++)
+    for(int k = 0; k < 8; k++) t[k] += h.v[sl][k];
+  out->rays_closest = t[0]; out->rays_shadow = t[1]; out->hits = t[2]; out->diffuse_hits = t[3];
+  out->tex_taps = t[4]; out->pixels = t[5]; out->nodes_visited = t[6]; out->tris_tested = t[7];
   return VKRT_OK;
 }
 
@@ -475,6 +587,34 @@ int vkrt_last_trace_ms(vkrt_scene* s, float* ms)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "no trace has been launched on this scene");
   HIP_TRY(hipEventSynchronize(s->evStop));
   HIP_TRY(hipEventElapsedTime(ms, s->evStart, s->evStop));
+  return VKRT_OK;
+}
+
+int vkrt_last_trace_timing(vkrt_scene* s, vkrt_trace_timing* out)
+{
+  if(!s || !out)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(!s->timed)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "no trace has been launched on this scene");
+  memset(out, 0, sizeof *out);
+  HIP_TRY(hipEventSynchronize(s->evStop));
+  HIP_TRY(hipEventElapsedTime(&out->total_ms, s->evStart, s->evStop));
+  out->mode = useWavefront() ? 1u : 0u;
+  if(s->wfTimed)
+  {
+    for(int k = 0; k < s->wfTiming.used; k++)
+    {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, s->wfEvents[2 * k], s->wfEvents[2 * k + 1]));
+      out->traverse_ms += ms;
+    }
+    out->traverse_launches = (uint32_t)s->wfTiming.used;
+  }
+  else if(!useWavefront())
+  {
+    out->traverse_ms = out->total_ms;
+    out->traverse_launches = 1;
+  }
   return VKRT_OK;
 }
 

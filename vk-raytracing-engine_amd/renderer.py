@@ -108,6 +108,12 @@ class Renderer:
         _check(self.lib.vkrt_last_trace_ms(self._h, C.byref(ms)), "vkrt_last_trace_ms")
         return float(ms.value)
 
+    def last_trace_timing(self):
+        t = abi.TraceTiming()
+        _check(self.lib.vkrt_last_trace_timing(self._h, C.byref(t)), "vkrt_last_trace_timing")
+        return {"total_ms": float(t.total_ms), "traverse_ms": float(t.traverse_ms), "traverse_launches": int(t.traverse_launches),
+                "mode": "wavefront" if t.mode == 1 else "megakernel"}
+
     def trace_rays(self, origins, directions, tmin=0.001, tmax=10000.0, any_hit=False):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
