@@ -111,11 +111,8 @@ struct TraceParams
 // Wavefront-mode working set (wavefront.hip): per-path SoA state, ray / hit records, two queues.
 struct WfBuffers
 {
-  unsigned* ctrl;       // [0],[1] queue counts, [2] traversal cursor
-  float4* S[8];         // path state
-  float4* R0;           // ray origin.xyz, tmax
-  float4* R1;           // ray direction.xyz, anyHit flag
-  float4* H;            // hit t,u,v,slot
-  unsigned* queue[2];   // path ids
+  unsigned* ctrl;       // queue counts [parity*2 + type], type 0 = closest-hit rays, 1 = shadow rays
+  float4* rec;          // 12 float4 (192 B) per path: ray + hit | state | state (wavefront.hip)
+  unsigned* queue[4];   // path ids, [parity*2 + type]
   uint32_t capacity;    // paths
 };
