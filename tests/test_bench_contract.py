@@ -1,0 +1,44 @@
+"""CPU-side checks of the measurement harness: weak-scaling image sizes, the algorithmic-bytes fixture and the
+committed round profile follow the bench contract."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_weak_scaling_image_sizes():
+    import bench
+
+    assert bench.image_size(1, 1920, 1080) == (1920, 1080)
+    assert bench.image_size(4, 1920, 1080) == (3840, 2160)  # BASELINE config 4 resolution
+    for n in (2, 8):
+        w, h = bench.image_size(n, 1920, 1080)
+        assert w % 8 == 0 and abs(w * h / (n * 1920 * 1080) - 1) < 0.01 and abs(w / h - 16 / 9) < 0.01
+
+
+def test_algorithmic_bytes_fixture_and_formula():
+    import oracle_py
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "algbytes.json")))["atrium262k_1080p_16spp_d8"]
+    assert 1000 < fx["traversal_bytes_per_ray"] < fx["bytes_per_ray"] < 6000  # SURVEY 8d expectation: 2-5 KB/ray
+    c = dict(nodes_visited=10, tris_tested=3, hits=2, diffuse_hits=1, tex_taps=4, pixels=5)
+    assert oracle_py.algorithmic_bytes(c) == 64 * 10 + 48 * 3 + 220 * 2 + 32 + 16 * 4 + 16 * 5
+    assert oracle_py.algorithmic_bytes(c, frame_gt0=True) == oracle_py.algorithmic_bytes(c) + 16 * 5
+
+
+def test_committed_bench_line_follows_contract():
+    path = os.path.join(ROOT, "profiles", "r01_bench.json")
+    if not os.path.exists(path):
+        import pytest
+
+        pytest.skip("no committed bench line yet")
+    d = json.loads(open(path).read())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "Mrays/s" and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1

@@ -1,0 +1,46 @@
+"""Turns gpurun_out/final/ (tools/final_round.sh) into the tracked files under profiles/:
+  <tag>_bench.json, <tag>_kernel_stats.csv, pmc_traffic.json (HBM-side bytes per launch of the dominant kernel)."""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "final")
+prof = os.path.join(ROOT, "profiles")
+line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith("{")][-1]
+open(os.path.join(prof, f"{tag}_bench.json"), "w").write(line)
+shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0], os.path.join(prof, f"{tag}_kernel_stats.csv"))
+
+
+def per_kernel(dirname, counter):
+    f = glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv"))[0]
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            k = r["Kernel_Name"].split("(")[0]
+            tot[k] += float(r["Counter_Value"])
+            n[k] += 1
+    return tot, n
+
+
+fetch, nf = per_kernel("pmc_fetch", "FETCH_SIZE")
+write, nw = per_kernel("pmc_write", "WRITE_SIZE")
+out = {"unit": "bytes", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) on `python3 bench.py --no-cpu-baseline`",
+       "note": "FETCH_SIZE/WRITE_SIZE are in KiB at the L2<->fabric interface (Infinity-Cache hits included). On gfx950 FETCH_SIZE "
+               "reads 1/2 of the bytes of wide coalesced streams (MI355X_MICROARCH.md, HBM); the guide's x2 correction is applied to the "
+               "read side as an upper bound -- this kernel's reads are scattered 16-B gathers, for which the counter is uncalibrated, so "
+               "both raw and corrected figures are kept.", "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    if not k.strip().startswith(("void k_wf", "k_wf", "void k_pathtrace", "k_pathtrace")):
+        continue
+    launches = max(nf.get(k, 0), nw.get(k, 0), 1)
+    rd_raw = fetch.get(k, 0.0) * 1024 / max(nf.get(k, 1), 1)
+    wr = write.get(k, 0.0) * 1024 / max(nw.get(k, 1), 1)
+    out["kernels"][k.strip()] = {"launches_profiled": launches, "read_bytes_per_launch_raw": rd_raw, "read_bytes_per_launch_x2": 2 * rd_raw,
+                                 "write_bytes_per_launch": wr}
+dom = next((k for k in out["kernels"] if "traverse" in k or "pathtrace" in k), None)
+if dom:
+    out["dominant_kernel"] = dom
+    out["hbm_bytes_per_launch"] = out["kernels"][dom]["read_bytes_per_launch_x2"] + out["kernels"][dom]["write_bytes_per_launch"]
+    out["hbm_bytes_per_launch_raw"] = out["kernels"][dom]["read_bytes_per_launch_raw"] + out["kernels"][dom]["write_bytes_per_launch"]
+json.dump(out, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])

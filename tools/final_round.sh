@@ -1,0 +1,17 @@
+#!/bin/bash
+# One gpurun call producing the artefacts kept under profiles/: GPU tests, default bench line, rocprofv3
+# kernel-trace stats of the same command, and separate --pmc passes for FETCH_SIZE / WRITE_SIZE.
+set -o pipefail
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; TAG=${1:-r01}
+rm -rf $OUT; mkdir -p $OUT
+step() { local name=$1 secs=$2; shift 2; timeout -k 10 $secs "$@" > $OUT/$name.log 2>&1; local rc=$?; echo "$name rc=$rc" | tee -a $OUT/round.log; [ $rc -ge 124 ] && { echo TIMEOUT | tee -a $OUT/round.log; exit $rc; }; return 0; }
+: > $OUT/round.log
+step pytest 600 python -m pytest tests -m gpu -q
+step bench 600 python bench.py
+export TMPDIR=/tmp
+cd /tmp
+step stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline
+step pmc_fetch 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline
+step pmc_write 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --no-cpu-baseline
+cd $R
+tail -3 $OUT/pytest.log; tail -1 $OUT/bench.log | cut -c1-400; cat $OUT/stats/*/*kernel_stats.csv | cut -c1-150 | head -6

@@ -140,13 +140,12 @@ VKRT_DEV f3 getSpecularBRDF_over_pdf_Cook_Torrance(f3 N, f3 H, f3 V, f3 L, f3 F0
   float down = 4.0f * fabsf(dot3(V, N)) * fabsf(dot3(L, N)) + 1e-4f;
   return (F * G / down) / pdf;
 }
-// gltf.glsl:111-134
-VKRT_DEV f3 computePBR_BRDF(const DevScene& sc, f3 N, f3 V, f3 L, f3 H, const GltfPBRMaterial& mat, float tu, float tv,
-                            ShadeStats& st)
+// gltf.glsl:111-134.  The GLSL re-evaluates pbrGetBaseColor / pbrGetMetallicRoughness here with the same
+// material and texCoord the caller (rchit:111-113) already used; those are pure functions, so the caller's
+// values (baseColor and the UNCLAMPED metalness / roughness) are passed in instead of fetching the
+// textures a second time.  The reference's texture() calls are still counted (retap).
+VKRT_DEV f3 computePBR_BRDF(f3 N, f3 V, f3 L, f3 H, f3 baseColor, float metalness, float roughness)
 {
-  f3 baseColor = pbrGetBaseColor(sc, mat, tu, tv, st);
-  float metalness, roughness;
-  pbrGetMetallicRoughness(sc, mat, tu, tv, metalness, roughness, st);
   f3 F0 = mk3(0.04f);
   F0 = glsl_mix(F0, baseColor, metalness);
   f3 F = getF_Schlick(H, V, F0);
@@ -158,8 +157,8 @@ VKRT_DEV f3 computePBR_BRDF(const DevScene& sc, f3 N, f3 V, f3 L, f3 H, const Gl
   return diffuse + f_cook_torrance;
 }
 // gltf.glsl:136-154 (non-point lights: 0, with Li = 0 and cosTheta = 0)
-VKRT_DEV f3 directLight(const DevScene& sc, const GltfLight& light, f3 P, f3 N, f3 V, const GltfPBRMaterial& mat, float tu,
-                        float tv, f3& Li, float& cosTheta, ShadeStats& st)
+VKRT_DEV f3 directLight(const GltfLight& light, f3 P, f3 N, f3 V, f3 baseColor, float metalness, float roughness, unsigned retap,
+                        f3& Li, float& cosTheta, ShadeStats& st)
 {
   Li = mk3(0.0f);
   cosTheta = 0.0f;
@@ -173,7 +172,10 @@ VKRT_DEV f3 directLight(const DevScene& sc, const GltfLight& light, f3 P, f3 N, 
     Li = mk3(light.color[0], light.color[1], light.color[2]) * light.intensity / attenuation;
     cosTheta = glsl_max(dot3(L, N), 0.0f);
     if(cosTheta > 0.0f)
-      return computePBR_BRDF(sc, N, V, L, H, mat, tu, tv, st);
+    {
+      st.taps += retap;
+      return computePBR_BRDF(N, V, L, H, baseColor, metalness, roughness);
+    }
   }
   return mk3(0.0f);
 }
@@ -269,6 +271,8 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
   const f3 V = normalize3(-worldRayDir);
   const f3 N = texNormal;
 
+  const float metalU = metalness, roughU = roughness;  // unclamped values, as directLight re-derives them
+  const unsigned retap = (mat.pbrBaseColorTexture > -1 ? 1u : 0u) + (mat.metallicRoughnessTexture > -1 ? 1u : 0u);
   const float ratio = 0.5f * (1.0f - metalness);  // rchit:127 (before the clamps)
   roughness = glsl_clamp(roughness, 0.01f, 0.99f);
   metalness = glsl_clamp(metalness, 0.01f, 0.99f);
@@ -295,7 +299,7 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
     {
       f3 Li;
       float cosTheta;
-      const f3 brdf = directLight(sc, light, worldPos, texNormal, V, mat, tu, tv, Li, cosTheta, st);
+      const f3 brdf = directLight(light, worldPos, texNormal, V, baseColor, metalU, roughU, retap, Li, cosTheta, st);
       emittance = emittance + (float)pc.lightsCount * brdf * Li * cosTheta;
     }
     rayDirection = normalize3(samplingHemisphere(prd.seed, tangent, binormal, texNormal));
