@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--fixed-size", action="store_true", help="keep --width/--height for every N (strong scaling)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo for rehearsals")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="all ranks use cuda:0 (control-flow rehearsal on a 1-GPU box; needs --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,10 +86,17 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    if args.rehearse_on_one_gpu:
+        assert args.backend == "gloo", "--rehearse-on-one-gpu needs --backend gloo (RCCL refuses two ranks on one device)"
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     W, H = (args.width, args.height) if args.fixed_size else image_size(world, args.width, args.height)
     flat, info = atrium.build_atrium(args.triangles, seed=args.scene_seed, with_textures=not args.no_textures)
@@ -105,7 +114,7 @@ def main():
         pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
         r.pathtrace(pc, cam, W, H, seed=frame, flags=flags, shard=shard, image=image, stream=stream)
         if world > 1:
-            return gather_image(image, H, world, rank)
+            return gather_image(image if args.backend == "nccl" else image.cpu(), H, world, rank)
         return image
 
     def sync():
@@ -146,8 +155,8 @@ def main():
     cnt_after = r.counters()
     rays_extra = (cnt_after["rays_closest"] + cnt_after["rays_shadow"]) - rays_local
     rays_per_launch_local = rays_extra / max(1, len(frame_ms))
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rr = torch.tensor([float(rays_local)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    rr = torch.tensor([float(rays_local)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)

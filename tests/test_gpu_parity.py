@@ -327,3 +327,22 @@ def test_wavefront_and_megakernel_modes_agree(cornell_flat):
         subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
         mega = np.load(out)
     assert np.array_equal(img.view(np.uint32), mega.view(np.uint32))
+
+
+def test_bench_multi_rank_rehearsal(tmp_path):
+    """The N>1 control flow of bench.py (strip shards, gather, max-over-ranks timing, rank-0 JSON) launched the way the
+    driver launches it, with 2 ranks sharing the one GPU over gloo (RCCL needs one device per rank)."""
+    import json, os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--rehearse-on-one-gpu", "--triangles", "20000", "--width", "640", "--height", "360", "--spp", "2", "--depth", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2
+    assert d["config"]["width"] * d["config"]["height"] > 640 * 360 * 1.9  # 2x the pixels for 2 ranks
