@@ -21,6 +21,11 @@ for spp, depth in ((1, 1), (1, 8), (4, 8)):
         torch.cuda.synchronize()
         t = r.last_trace_timing(); c = r.counters()
     rays = c["rays_closest"] + c["rays_shadow"]
+    r.reset_counters()
+    r.pathtrace(pc, cam, W, H, seed=1, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL, image=img)
+    cc = r.counters()
+    work = {"nodes_per_ray": round(cc["nodes_visited"] / rays, 2), "tris_per_ray": round(cc["tris_tested"] / rays, 2),
+            "shadow_frac": round(cc["rays_shadow"] / rays, 3)}
     print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("VKRT_")}, "spp": spp, "depth": depth, "rays": rays,
                       "total_ms": round(t["total_ms"], 3), "traverse_ms": round(t["traverse_ms"], 3), "launches": t["traverse_launches"],
-                      "Mrays_s_total": round(rays / t["total_ms"] / 1e3, 1), "Mrays_s_traverse": round(rays / max(t["traverse_ms"], 1e-9) / 1e3, 1), "mode": t["mode"]}))
+                      "Mrays_s_total": round(rays / t["total_ms"] / 1e3, 1), "Mrays_s_traverse": round(rays / max(t["traverse_ms"], 1e-9) / 1e3, 1), "mode": t["mode"], **work}))

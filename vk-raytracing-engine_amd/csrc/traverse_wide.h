@@ -18,130 +18,161 @@
 
 VKRT_DEV float ubyte_f32(unsigned w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
-template <bool COUNT>
-VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, uint2* stk, int stride, RayHit& hit,
-                             unsigned& nNodes, unsigned& nTris)
+// Resumable per-lane traversal state: one w8_iterate() = take the nearest pending child node of the
+// current group, test its 8 children, intersect the triangles the ray's boxes touched, then pop if the
+// group is exhausted.  Used as a plain loop (traverse_wide8) and by the refilling kernel (wavefront.hip).
+struct W8State
 {
-  const f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-  const bool px = !(id.x < 0.0f), py = !(id.y < 0.0f), pz = !(id.z < 0.0f);
-  const unsigned octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+  f3 o, d, id;
+  float tmax, bestT, bestU, bestV;
+  int bestSlot, bestGid;
+  uint2 G;
+  int sp;
+  unsigned steps;
+  bool anyHit;
+};
+
+VKRT_DEV void w8_begin(const DevScene& sc, W8State& S, f3 o, f3 d, float tmax, bool anyHit)
+{
+  S.o = o; S.d = d;
+  S.id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  S.tmax = tmax; S.bestT = tmax; S.bestU = 0.0f; S.bestV = 0.0f;
+  S.bestSlot = -1; S.bestGid = -1;
+  S.G = make_uint2(0u, sc.rootRef == VKRT_TRAV_DONE ? 0u : 0x80000000u);
+  S.sp = 0;
+  S.steps = sc.stepLimit;
+  S.anyHit = anyHit;
+}
+
+// returns true while the ray has more work
+template <bool COUNT>
+VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk, int stride, unsigned& nNodes, unsigned& nTris)
+{
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
   const int cap = (int)(sc.stackCap >> 1);
-  float bestT = tmax, bestU = 0.0f, bestV = 0.0f;
-  int bestSlot = -1, bestGid = -1;
-  uint2 G = make_uint2(0u, sc.rootRef == VKRT_TRAV_DONE ? 0u : 0x80000000u);
-  int sp = 0;
-  unsigned steps = sc.stepLimit;
-  bool done = false;
-  while(!done)
+  const f3 o = S.o, d = S.d, id = S.id;
+  const bool px = !(id.x < 0.0f), py = !(id.y < 0.0f), pz = !(id.z < 0.0f);
+  const unsigned octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+  uint2 G = S.G;
+  uint2 T = make_uint2(0u, 0u);
+  if(G.y & 0xff000000u)
   {
-    uint2 T = make_uint2(0u, 0u);
-    if(G.y & 0xff000000u)
+    // take the nearest pending internal child of the group
+    const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
+    const unsigned slot = (bitIdx - 24u) ^ octinv;
+    const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
+    G.y &= ~(1u << bitIdx);
+    if((G.y & 0xff000000u) && S.sp < cap)
     {
-      // take the nearest pending internal child of the group
-      const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
-      const unsigned slot = (bitIdx - 24u) ^ octinv;
-      const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
-      G.y &= ~(1u << bitIdx);
-      if((G.y & 0xff000000u) && sp < cap)
-      {
-        stk[sp * stride] = G;
-        sp++;
-      }
-      if(--steps == 0u)
-        break;
-      const float4 q0 = nodes[child * VKRT_WNODE_QUADS + 0];
-      const float4 q1 = nodes[child * VKRT_WNODE_QUADS + 1];
-      const float4 q2 = nodes[child * VKRT_WNODE_QUADS + 2];
-      const float4 q3 = nodes[child * VKRT_WNODE_QUADS + 3];
-      const float4 q4 = nodes[child * VKRT_WNODE_QUADS + 4];
-      if(COUNT) nNodes++;
-      const unsigned ew = __float_as_uint(q0.w);
-      const unsigned imask = ew >> 24;
-      const float asx = __uint_as_float((ew & 0xffu) << 23) * id.x;
-      const float asy = __uint_as_float(((ew >> 8) & 0xffu) << 23) * id.y;
-      const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
-      const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
-      const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox);
-      const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy);
-      const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz);
-      // quantised planes, near/far by ray direction sign
-      const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
-      const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
-      const unsigned hy0 = __float_as_uint(q4.x), hy1 = __float_as_uint(q4.y), hz0 = __float_as_uint(q4.z), hz1 = __float_as_uint(q4.w);
-      const unsigned nx[2] = {px ? lx0 : hx0, px ? lx1 : hx1}, fx[2] = {px ? hx0 : lx0, px ? hx1 : lx1};
-      const unsigned ny[2] = {py ? ly0 : hy0, py ? ly1 : hy1}, fy[2] = {py ? hy0 : ly0, py ? hy1 : ly1};
-      const unsigned nz[2] = {pz ? lz0 : hz0, pz ? lz1 : hz1}, fz[2] = {pz ? hz0 : lz0, pz ? hz1 : lz1};
-      const unsigned metaW[2] = {__float_as_uint(q1.z), __float_as_uint(q1.w)};
-      unsigned hitmask = 0u;
-#pragma unroll
-      for(int i = 0; i < 8; i++)
-      {
-        const int w = i >> 2, k = i & 3;
-        const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), asx, fox);
-        const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), asy, foy);
-        const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), asz, foz);
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT));
-        const unsigned meta = (metaW[w] >> (8 * k)) & 0xffu;
-        const bool inner = ((imask >> i) & 1u) != 0u;
-        const unsigned bits = inner ? 1u : (meta >> 5);
-        const unsigned bitIndex = inner ? (24u + ((unsigned)i ^ octinv)) : (meta & 31u);
-        if(tn <= tf * 1.000001f)
-          hitmask |= bits << bitIndex;
-      }
-      G = make_uint2(__float_as_uint(q1.x), (hitmask & 0xff000000u) | imask);
-      T = make_uint2(__float_as_uint(q1.y), hitmask & 0x00ffffffu);
+      stk[S.sp * stride] = G;
+      S.sp++;
     }
-    // triangles of this node that the ray's boxes touched
-    while(T.y != 0u)
+    if(--S.steps == 0u)
+      return false;
+    const float4 q0 = nodes[child * VKRT_WNODE_QUADS + 0];
+    const float4 q1 = nodes[child * VKRT_WNODE_QUADS + 1];
+    const float4 q2 = nodes[child * VKRT_WNODE_QUADS + 2];
+    const float4 q3 = nodes[child * VKRT_WNODE_QUADS + 3];
+    const float4 q4 = nodes[child * VKRT_WNODE_QUADS + 4];
+    if(COUNT) nNodes++;
+    const unsigned ew = __float_as_uint(q0.w);
+    const unsigned imask = ew >> 24;
+    const float asx = __uint_as_float((ew & 0xffu) << 23) * id.x;
+    const float asy = __uint_as_float(((ew >> 8) & 0xffu) << 23) * id.y;
+    const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
+    const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
+    const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox);
+    const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy);
+    const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz);
+    // quantised planes, near/far by ray direction sign
+    const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
+    const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
+    const unsigned hy0 = __float_as_uint(q4.x), hy1 = __float_as_uint(q4.y), hz0 = __float_as_uint(q4.z), hz1 = __float_as_uint(q4.w);
+    const unsigned nx[2] = {px ? lx0 : hx0, px ? lx1 : hx1}, fx[2] = {px ? hx0 : lx0, px ? hx1 : lx1};
+    const unsigned ny[2] = {py ? ly0 : hy0, py ? ly1 : hy1}, fy[2] = {py ? hy0 : ly0, py ? hy1 : ly1};
+    const unsigned nz[2] = {pz ? lz0 : hz0, pz ? lz1 : hz1}, fz[2] = {pz ? hz0 : lz0, pz ? hz1 : lz1};
+    const unsigned metaW[2] = {__float_as_uint(q1.z), __float_as_uint(q1.w)};
+    const float bestT = S.bestT;
+    unsigned hitmask = 0u;
+#pragma unroll
+    for(int i = 0; i < 8; i++)
     {
-      const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
-      T.y &= T.y - 1u;
-      if(--steps == 0u) { done = true; break; }
-      const unsigned s = T.x + i;
-      const float4 a = tris[s * VKRT_TRI_QUADS + 0];
-      const float4 b = tris[s * VKRT_TRI_QUADS + 1];
-      const float4 c = tris[s * VKRT_TRI_QUADS + 2];
-      if(COUNT) nTris++;
-      float t, u, v;
-      if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
+      const int w = i >> 2, k = i & 3;
+      const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), asx, fox);
+      const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), asy, foy);
+      const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), asz, foz);
+      const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT));
+      const unsigned meta = (metaW[w] >> (8 * k)) & 0xffu;
+      const bool inner = ((imask >> i) & 1u) != 0u;
+      const unsigned bits = inner ? 1u : (meta >> 5);
+      const unsigned bitIndex = inner ? (24u + ((unsigned)i ^ octinv)) : (meta & 31u);
+      if(tn <= tf * 1.000001f)
+        hitmask |= bits << bitIndex;
+    }
+    G = make_uint2(__float_as_uint(q1.x), (hitmask & 0xff000000u) | imask);
+    T = make_uint2(__float_as_uint(q1.y), hitmask & 0x00ffffffu);
+  }
+  // triangles of this node that the ray's boxes touched
+  while(T.y != 0u)
+  {
+    const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
+    T.y &= T.y - 1u;
+    if(--S.steps == 0u)
+      return false;
+    const unsigned s = T.x + i;
+    const float4 a = tris[s * VKRT_TRI_QUADS + 0];
+    const float4 b = tris[s * VKRT_TRI_QUADS + 1];
+    const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+    if(COUNT) nTris++;
+    float t, u, v;
+    if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
+    {
+      if(t > tmin)
       {
-        if(t > tmin)
+        if(S.anyHit)
         {
-          if(anyHit)
+          if(t < S.tmax)
           {
-            if(t < tmax)
-            {
-              bestSlot = (int)s;
-              bestT = t;
-              done = true;
-              break;
-            }
+            S.bestSlot = (int)s;
+            S.bestT = t;
+            return false;
           }
-          else
+        }
+        else
+        {
+          const int gid = __float_as_int(c.y);
+          if(t < S.bestT || (t == S.bestT && gid < S.bestGid))
           {
-            const int gid = __float_as_int(c.y);
-            if(t < bestT || (t == bestT && gid < bestGid))
-            {
-              bestT = t; bestU = u; bestV = v; bestSlot = (int)s; bestGid = gid;
-            }
+            S.bestT = t; S.bestU = u; S.bestV = v; S.bestSlot = (int)s; S.bestGid = gid;
           }
         }
       }
     }
-    if(done)
-      break;
-    if((G.y & 0xff000000u) == 0u)
-    {
-      if(sp == 0)
-        break;
-      sp--;
-      G = stk[sp * stride];
-    }
   }
-  hit.t = bestT; hit.u = bestU; hit.v = bestV; hit.slot = bestSlot;
+  if((G.y & 0xff000000u) == 0u)
+  {
+    if(S.sp == 0)
+      return false;
+    S.sp--;
+    G = stk[S.sp * stride];
+  }
+  S.G = G;
+  return true;
+}
+
+template <bool COUNT>
+VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, uint2* stk, int stride, RayHit& hit,
+                             unsigned& nNodes, unsigned& nTris)
+{
+  W8State S;
+  w8_begin(sc, S, o, d, tmax, anyHit);
+  if(S.G.y != 0u)
+    while(w8_iterate<COUNT>(sc, S, tmin, stk, stride, nNodes, nTris))
+    {
+    }
+  hit.t = S.bestT; hit.u = S.bestU; hit.v = S.bestV; hit.slot = S.bestSlot;
 }
 
 // layout dispatch used by the kernels: stkWords = this lane's LDS stack column (4-byte words, stride in words)

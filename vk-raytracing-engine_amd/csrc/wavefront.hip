@@ -210,6 +210,116 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse(const TraceParams P, c
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 8 : 2, red);
 }
 
+// ---- traversal variant: persistent workgroups, idle lanes refilled from the queue inside the loop ------------------
+// (wide8 only; VKRT_WF_TRAVERSE=refill).  Workgroups are still homogeneous in ray type; a wave owns a private
+// chunk of queue slots (one global atomic per WF_CHUNK rays) and refills when >= refillMin lanes are idle.
+#define WF_CHUNK 128u
+template <bool COUNT>
+__global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse_refill(const TraceParams P, const WfBuffers B, const int round, const unsigned refillMin)
+{
+  extern __shared__ int lds_stack[];
+  uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
+  const unsigned lane = lane_id();
+  const int par = round & 1;
+  const unsigned countC = B.ctrl[par * 2 + 0], countS = B.ctrl[par * 2 + 1];
+  if(blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    B.ctrl[(par ^ 1) * 2 + 0] = 0u;
+    B.ctrl[(par ^ 1) * 2 + 1] = 0u;
+  }
+  // split the persistent grid between the two queues in proportion to their lengths
+  const unsigned total = countC + countS;
+  if(total == 0u)
+    return;
+  unsigned blocksS = (unsigned)(((unsigned long long)gridDim.x * countS + total - 1u) / total);
+  if(countS == 0u) blocksS = 0u;
+  if(countC != 0u && blocksS >= gridDim.x) blocksS = gridDim.x - 1u;
+  const bool anyHit = blockIdx.x < blocksS;
+  const unsigned count = anyHit ? countS : countC;
+  const unsigned* __restrict__ queue = qPtr(B, par, anyHit ? 1 : 0);
+  unsigned* cursor = &B.ctrl[4 + (anyHit ? 1 : 0)];
+
+  bool active = false, exhausted = false;
+  unsigned chunkNext = 0, chunkEnd = 0, pid = 0;
+  W8State S;
+  S.G = make_uint2(0u, 0u); S.sp = 0; S.steps = 0; S.anyHit = anyHit;
+  S.o = mk3(0.0f); S.d = mk3(0.0f); S.id = mk3(0.0f); S.tmax = 0.0f; S.bestT = 0.0f; S.bestU = 0.0f; S.bestV = 0.0f; S.bestSlot = -1; S.bestGid = -1;
+  unsigned nRays = 0, nNodes = 0, nTris = 0;
+  for(;;)
+  {
+    const unsigned long long idleMask = __ballot(!active);
+    if(idleMask != 0ull && (chunkNext < chunkEnd || !exhausted))
+    {
+      const unsigned nIdle = (unsigned)__popcll(idleMask);
+      if(nIdle >= refillMin || idleMask == ~0ull)
+      {
+        const unsigned rank = (unsigned)__popcll(idleMask & ((1ull << lane) - 1ull));
+        const unsigned avail = chunkEnd - chunkNext;
+        unsigned qi = 0xffffffffu;
+        if(nIdle <= avail)
+        {
+          qi = chunkNext + rank;
+          chunkNext += nIdle;
+        }
+        else
+        {
+          unsigned nb = 0, ne = 0;
+          if(!exhausted)
+          {
+            const unsigned leader = (unsigned)__ffsll((long long)idleMask) - 1u;
+            unsigned base = 0;
+            if(lane == leader)
+              base = atomicAdd(cursor, WF_CHUNK);
+            base = (unsigned)__shfl((int)base, (int)leader);
+            if(base >= count)
+              exhausted = true;
+            else
+            {
+              nb = base;
+              ne = min(base + WF_CHUNK, count);
+            }
+          }
+          if(rank < avail)
+            qi = chunkNext + rank;
+          else if(rank - avail < ne - nb)
+            qi = nb + (rank - avail);
+          chunkNext = nb + min(nIdle - avail, ne - nb);
+          chunkEnd = ne;
+        }
+        if(!active && qi != 0xffffffffu)
+        {
+          pid = queue[qi];
+          const float4* r = rec(B, pid);
+          const float4 r0 = r[0], r1 = r[1];
+          w8_begin(P.sc, S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, anyHit);
+          active = S.G.y != 0u;
+          if(!active)
+            rec(B, pid)[2] = make_float4(S.bestT, 0.0f, 0.0f, __int_as_float(-1));
+          nRays++;
+        }
+      }
+    }
+    const unsigned long long liveMask = __ballot(active);
+    if(liveMask == 0ull)
+    {
+      if(exhausted && chunkNext >= chunkEnd)
+        break;
+      continue;
+    }
+    if(active)
+    {
+      if(!w8_iterate<COUNT>(P.sc, S, 0.001f, stk, WF_BLOCK, nNodes, nTris))
+      {
+        rec(B, pid)[2] = make_float4(S.bestT, S.bestU, S.bestV, __int_as_float(S.bestSlot));
+        active = false;
+      }
+    }
+  }
+  __shared__ unsigned long long red[8 * (WF_BLOCK / 64)];
+  const unsigned vals[8] = {anyHit ? 0u : nRays, anyHit ? nRays : 0u, 0, 0, 0, 0, nNodes, nTris};
+  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 8 : 2, red);
+}
+
 // ---- shade, closest-hit results: rchit / rmiss, then shadow request or accumulation (heavy; few waves/SIMD) ---------
 __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_closest(const TraceParams P, const WfBuffers B, const int round)
 {
@@ -296,7 +406,6 @@ void vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B)
 
 hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing)
 {
-  (void)cuCount;
   const unsigned work = P.tileCount * 64u;
   hipError_t e = hipMemsetAsync(B.ctrl, 0, 64, stream);
   if(e != hipSuccess)
@@ -313,12 +422,34 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int c
   const int rounds = 2 * P.pc.samples * P.pc.depth;
   if(timing)
     timing->used = 0;
+  static int refill = -1, refillMin = 16, refillBlocks = 0;
+  if(refill < 0)
+  {
+    const char* e = getenv("VKRT_WF_TRAVERSE");
+    refill = (e && !strcmp(e, "refill")) ? 1 : 0;
+    if((e = getenv("VKRT_WF_REFILL"))) refillMin = std::max(1, std::min(64, atoi(e)));
+    if((e = getenv("VKRT_WF_BLOCKS_PER_CU"))) refillBlocks = atoi(e);
+  }
+  int perCU = 4;
+  if(refill && wide)
+  {
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_wf_traverse_refill<false>, WF_BLOCK, lds);
+    if(refillBlocks > 0) perCU = std::min(perCU, refillBlocks);
+    perCU = std::max(perCU, 1);
+  }
   for(int r = 0; r < rounds; r++)
   {
     const bool timed = timing && timing->events && 2 * (timing->used + 1) <= timing->capacity;
     if(timed)
       (void)hipEventRecord(timing->events[2 * timing->used], stream);
-    if(wide)
+    if(wide && refill)
+    {
+      (void)hipMemsetAsync(&B.ctrl[4], 0, 8, stream);
+      const dim3 pg((unsigned)std::min<long long>((long long)cuCount * perCU, (long long)blocks + 2));
+      if(count) hipLaunchKernelGGL(k_wf_traverse_refill<true>, pg, bb, lds, stream, P, B, r, (unsigned)refillMin);
+      else hipLaunchKernelGGL(k_wf_traverse_refill<false>, pg, bb, lds, stream, P, B, r, (unsigned)refillMin);
+    }
+    else if(wide)
     {
       if(count) hipLaunchKernelGGL((k_wf_traverse<true, true>), grid, bb, lds, stream, P, B, r);
       else hipLaunchKernelGGL((k_wf_traverse<false, true>), grid, bb, lds, stream, P, B, r);
