@@ -278,6 +278,22 @@ void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh
   out.sahCost = (float)cost;
 }
 
+void pack_tri_shade(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, const uint32_t* indices, const vkrt_prim_mesh* pm,
+                    const vkrt_node* nodes, std::vector<uint32_t>& out)
+{
+  out.resize(order.size() * 4);
+  for(size_t s = 0; s < order.size(); s++)
+  {
+    const FlatTri& t = tris[order[s]];
+    const vkrt_prim_mesh& p = pm[nodes[t.inst].primMesh];
+    const uint32_t base = p.firstIndex + 3u * t.prim;
+    out[4 * s + 0] = indices[base + 0] + p.vertexOffset;
+    out[4 * s + 1] = indices[base + 1] + p.vertexOffset;
+    out[4 * s + 2] = indices[base + 2] + p.vertexOffset;
+    out[4 * s + 3] = (uint32_t)std::max(0, p.materialIndex);
+  }
+}
+
 void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out)
 {
   out.resize(order.size() * 12);

@@ -33,6 +33,10 @@ void flatten_instances(const float* positions, const uint32_t* indices, const vk
 
 void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh& out);
 
+// 16-byte shading records in slot order: absolute vertex indices + max(0, materialIndex) (raytrace.rchit:34-50)
+void pack_tri_shade(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, const uint32_t* indices, const vkrt_prim_mesh* pm,
+                    const vkrt_node* nodes, std::vector<uint32_t>& out);
+
 // 48-byte device triangle records in slot order
 void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out);
 

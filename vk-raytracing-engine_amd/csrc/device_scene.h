@@ -74,6 +74,7 @@ struct DevScene
   const float* srgbLut;       // 256 floats
   const float4* nodes;
   const float4* tris;
+  const uint4* triShade;      // per triangle slot: absolute vertex indices i0,i1,i2 and max(0, materialIndex)
   uint32_t textureCount;
   uint32_t triCount;
   int32_t rootRef;            // 0 (internal root) or a leaf ref for tiny scenes

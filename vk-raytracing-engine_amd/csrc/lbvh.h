@@ -13,6 +13,7 @@ struct LbvhResult
 {
   void* nodes = nullptr;  // device, 64 B per node (caller frees with hipFree)
   void* tris = nullptr;   // device, 48 B per triangle in leaf order
+  void* triShade = nullptr;  // device, 16 B per triangle in leaf order (vertex indices + material)
   uint32_t triCount = 0, nodeCount = 0, maxDepth = 0;
   int32_t rootRef = (int32_t)0x80000000;
   float sahCost = 0;

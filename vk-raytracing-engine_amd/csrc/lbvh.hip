@@ -295,12 +295,19 @@ __global__ void k_emit(int n, const unsigned* order, const float* triBox, const 
   atomicAdd(sahAccum, cost);
 }
 
-__global__ void k_pack(unsigned n, const unsigned* order, const float4* triU, float4* outTris)
+__global__ void k_pack(unsigned n, const unsigned* order, const float4* triU, float4* outTris, FlatArgs A, const int* instMaterial,
+                       uint4* outShade)
 {
   const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
   if(s >= n)
     return;
   const unsigned g = order[s];
+  {  // shading record: absolute vertex indices + max(0, materialIndex) (raytrace.rchit:34-50)
+    const float4 c = triU[3 * (size_t)g + 2];
+    const unsigned inst = (unsigned)__float_as_int(c.z), prim = (unsigned)__float_as_int(c.w);
+    const uint32_t base = A.instFirstIndex[inst] + 3u * prim, vo = A.instVertexOffset[inst];
+    outShade[s] = make_uint4(A.indices[base] + vo, A.indices[base + 1] + vo, A.indices[base + 2] + vo, (uint32_t)max(0, instMaterial[inst]));
+  }
   outTris[3 * (size_t)s + 0] = triU[3 * (size_t)g + 0];
   outTris[3 * (size_t)s + 1] = triU[3 * (size_t)g + 1];
   outTris[3 * (size_t)s + 2] = triU[3 * (size_t)g + 2];
@@ -353,7 +360,8 @@ struct Temp
       out.error = std::string(#expr) + ": " + hipGetErrorString(e_); \
       if(out.nodes) (void)hipFree(out.nodes);                \
       if(out.tris) (void)hipFree(out.tris);                  \
-      out.nodes = out.tris = nullptr;                        \
+      if(out.triShade) (void)hipFree(out.triShade);          \
+      out.nodes = out.tris = out.triShade = nullptr;         \
       return e_ == hipErrorOutOfMemory ? VKRT_ERR_OUT_OF_MEMORY : VKRT_ERR_HIP; \
     }                                                        \
   } while(0)
@@ -363,24 +371,30 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
 {
   out = LbvhResult{};
   std::vector<uint32_t> firstGid(instCount + 1, 0), firstIndex(instCount, 0), vertexOffset(instCount, 0);
+  std::vector<int32_t> material(instCount, 0);
   for(uint32_t n = 0; n < instCount; n++)
   {
     const vkrt_prim_mesh& p = pm[nodes[n].primMesh];
     firstGid[n + 1] = firstGid[n] + p.indexCount / 3;
     firstIndex[n] = p.firstIndex;
     vertexOffset[n] = p.vertexOffset;
+    material[n] = p.materialIndex;
   }
   const uint32_t T = firstGid[instCount];
   out.triCount = T;
   out.rootRef = VKRT_TRAV_DONE;
   LB_TRY(hipMalloc(&out.nodes, std::max<size_t>((size_t)(T > 1 ? T - 1 : 1) * 64, 64)));
   LB_TRY(hipMalloc(&out.tris, std::max<size_t>((size_t)T * 48, 48)));
+  LB_TRY(hipMalloc(&out.triShade, std::max<size_t>((size_t)T * 16, 16)));
   out.nodeCount = T > 1 ? T - 1 : 0;
   if(T == 0)
     return VKRT_OK;
 
   Temp tmp;
   uint32_t *dFirstGid, *dFirstIndex, *dVertexOffset;
+  int32_t* dMaterial;
+  LB_TRY(tmp.alloc(&dMaterial, instCount));
+  LB_TRY(hipMemcpyAsync(dMaterial, material.data(), instCount * 4, hipMemcpyHostToDevice, stream));
   LB_TRY(tmp.alloc(&dFirstGid, instCount + 1));
   LB_TRY(tmp.alloc(&dFirstIndex, instCount));
   LB_TRY(tmp.alloc(&dVertexOffset, instCount));
@@ -416,7 +430,7 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
   LB_TRY(rocprim::radix_sort_pairs(sortTmp, sortBytes, keysA, keysB, valsA, valsB, (size_t)T, 0, 63, stream));
   const unsigned* order = valsB;
 
-  hipLaunchKernelGGL(k_pack, dim3(G), dim3(B), 0, stream, T, order, (const float4*)triU, (float4*)out.tris);
+  hipLaunchKernelGGL(k_pack, dim3(G), dim3(B), 0, stream, T, order, (const float4*)triU, (float4*)out.tris, A, (const int*)dMaterial, (uint4*)out.triShade);
   LB_TRY(hipGetLastError());
 
   if(T <= kLeaf)

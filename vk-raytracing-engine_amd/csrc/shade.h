@@ -206,13 +206,11 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
   const float4 rec = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
   const uint32_t instId = (uint32_t)__float_as_int(rec.z), primId = (uint32_t)__float_as_int(rec.w);
   const DevInstance in = sc.instances[instId];
-  const float4 pq = ((const float4*)sc.primInfo)[in.primMesh];  // rchit:34 (PrimMeshInfo, one 16-byte load)
-  const uint32_t indexOffset = __float_as_uint(pq.x) + 3u * primId;
-  const uint32_t vertexOffset = __float_as_uint(pq.y);
-  const uint32_t matIndex = (uint32_t)max(0, __float_as_int(pq.z));
-  const uint32_t i0 = sc.indices[indexOffset + 0] + vertexOffset;
-  const uint32_t i1 = sc.indices[indexOffset + 1] + vertexOffset;
-  const uint32_t i2 = sc.indices[indexOffset + 2] + vertexOffset;
+  // rchit:34-50 (PrimMeshInfo lookup, three index fetches, vertexOffset, max(0, materialIndex)) is resolved once
+  // per triangle at build time into a 16-byte record, so the attribute fetch below is one hop from the hit.
+  const uint4 ts = sc.triShade[hit.slot];
+  const uint32_t i0 = ts.x, i1 = ts.y, i2 = ts.z, matIndex = ts.w;
+  (void)primId;
   const f3 b = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);  // rchit:68
 
   const float4 a0 = sc.vertexPN[2 * i0], b0 = sc.vertexPN[2 * i0 + 1];

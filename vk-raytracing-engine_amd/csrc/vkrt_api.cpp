@@ -62,6 +62,7 @@ struct vkrt_scene
   DevScene dev{};
   void* accelNodes = nullptr;
   void* accelTris = nullptr;
+  void* accelShade = nullptr;
   bool built = false;
   vkrt_accel_info info{};
   unsigned int* workCounter = nullptr;
@@ -154,7 +155,8 @@ void freeAccel(vkrt_scene* s)
 {
   if(s->accelNodes) (void)hipFree(s->accelNodes);
   if(s->accelTris) (void)hipFree(s->accelTris);
-  s->accelNodes = s->accelTris = nullptr;
+  if(s->accelShade) (void)hipFree(s->accelShade);
+  s->accelNodes = s->accelTris = s->accelShade = nullptr;
   s->built = false;
 }
 
@@ -361,6 +363,12 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
       nodeData = bvh.nodes.data();
       nodeBytesUsed = bvh.nodes.size() * sizeof(float);
     }
+    std::vector<uint32_t> shadeRec;
+    vkrt::pack_tri_shade(tris, wide ? w8.triOrder : bvh.triOrder, s->indices.data(), s->primMeshes.data(), s->nodes.data(), shadeRec);
+    HIP_TRY(hipMalloc(&s->accelShade, std::max<size_t>(shadeRec.size() * 4, 16)));
+    if(!shadeRec.empty())
+      HIP_TRY(hipMemcpyAsync(s->accelShade, shadeRec.data(), shadeRec.size() * 4, hipMemcpyHostToDevice, stream));
+    s->dev.triShade = (const uint4*)s->accelShade;
     const size_t nodeBytes = std::max<size_t>(nodeBytesUsed, 80);
     const size_t triBytes = std::max<size_t>(packed.size() * sizeof(float), 48);
     HIP_TRY(hipMalloc(&s->accelNodes, nodeBytes));
@@ -403,6 +411,8 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
       return fail(rc, "LBVH build failed: %s", r.error.c_str());
     s->accelNodes = r.nodes;
     s->accelTris = r.tris;
+    s->accelShade = r.triShade;
+    s->dev.triShade = (const uint4*)r.triShade;
     s->dev.nodes = (const float4*)r.nodes;
     s->dev.tris = (const float4*)r.tris;
     s->dev.triCount = r.triCount;
