@@ -587,6 +587,14 @@ void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out)
     return;
   BuiltBvh b2;
   build_sah_host(tris, 1, b2);  // one triangle per binary leaf; the DP forms the <=3-triangle leaf children
+  collapse_wide8(b2, tris, out);
+}
+
+void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltWide8& out)
+{
+  out = BuiltWide8{};
+  if(tris.empty())
+    return;
   W8Ctx cx{b2, out};
   out.triOrder.reserve(tris.size());
   out.nodes.resize(20);
@@ -594,7 +602,7 @@ void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out)
   if(b2.rootRef < 0)
   {  // single triangle: a root with one leaf child
     W8Child c;
-    const FlatTri& t = tris[0];
+    const FlatTri& t = tris[b2.triOrder.empty() ? 0 : b2.triOrder[0]];
     for(int k = 0; k < 3; k++)
     {
       const float p0 = t.v0[k], p1 = t.v0[k] + t.e1[k], p2 = t.v0[k] + t.e2[k];

@@ -64,5 +64,8 @@ struct BuiltWide8
   float sahCost = 0;
 };
 void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out);
+// SAH-optimal collapse of an existing binary tree whose leaves hold <= 3 triangles each (ideally 1).
+// triCount0Box: bounds of the first triangle, used only when the binary root is a leaf.
+void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltWide8& out);
 
 }  // namespace vkrt

@@ -22,6 +22,6 @@ struct LbvhResult
 
 // sc must already hold the uploaded positions / indices / instances.
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out);
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4);
 
 }  // namespace vkrt

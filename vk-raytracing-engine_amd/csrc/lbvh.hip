@@ -25,7 +25,6 @@ namespace vkrt {
 
 namespace {
 
-constexpr unsigned kLeaf = 4;
 
 struct FlatArgs
 {
@@ -246,7 +245,7 @@ VKRT_DEV float boxArea(const float* b)
   return 2.0f * (dx * dy + dy * dz + dz * dx);
 }
 
-__global__ void k_emit(int n, const unsigned* order, const float* triBox, const int2* children, const int2* range, const float* nodeBox,
+__global__ void k_emit(unsigned kLeaf, int n, const unsigned* order, const float* triBox, const int2* children, const int2* range, const float* nodeBox,
                        float4* outNodes, float* sahAccum)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,7 +313,7 @@ __global__ void k_pack(unsigned n, const unsigned* order, const float4* triU, fl
 }
 
 // depth of the emitted tree = max over leaves of the number of emitted ancestors
-__global__ void k_depth(int n, const int2* range, const int* parentInternal, const int* parentLeaf, unsigned* maxDepth)
+__global__ void k_depth(unsigned kLeaf, int n, const int2* range, const int* parentInternal, const int* parentLeaf, unsigned* maxDepth)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if(k >= n)
@@ -367,8 +366,9 @@ struct Temp
   } while(0)
 
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out)
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize)
 {
+  const unsigned kLeaf = leafSize < 1u ? 1u : (leafSize > 8u ? 8u : leafSize);
   out = LbvhResult{};
   std::vector<uint32_t> firstGid(instCount + 1, 0), firstIndex(instCount, 0), vertexOffset(instCount, 0);
   std::vector<int32_t> material(instCount, 0);
@@ -460,9 +460,9 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
                      parentLeaf);
   hipLaunchKernelGGL(k_fit, dim3(G), dim3(B), 0, stream, (int)T, order, (const float*)triBox, (const int2*)children,
                      (const int*)parentInternal, (const int*)parentLeaf, nodeBox, arrive);
-  hipLaunchKernelGGL(k_emit, dim3(G), dim3(B), 0, stream, (int)T, order, (const float*)triBox, (const int2*)children, (const int2*)range,
+  hipLaunchKernelGGL(k_emit, dim3(G), dim3(B), 0, stream, kLeaf, (int)T, order, (const float*)triBox, (const int2*)children, (const int2*)range,
                      (const float*)nodeBox, (float4*)out.nodes, (float*)&scalars[1]);
-  hipLaunchKernelGGL(k_depth, dim3(G), dim3(B), 0, stream, (int)T, (const int2*)range, (const int*)parentInternal, (const int*)parentLeaf,
+  hipLaunchKernelGGL(k_depth, dim3(G), dim3(B), 0, stream, kLeaf, (int)T, (const int2*)range, (const int*)parentInternal, (const int*)parentLeaf,
                      &scalars[0]);
   LB_TRY(hipGetLastError());
   unsigned hs[4];

@@ -405,26 +405,83 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   }
   else
   {
+    const char* envBvh = getenv("VKRT_BVH");
+    const bool wide = useWavefront() && !(envBvh && !strcmp(envBvh, "bvh2"));
     vkrt::LbvhResult r;
-    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r);
+    // GPU radix-tree build (Morton codes, sort, Karras hierarchy, bottom-up fit).  For the trace-optimised layout the
+    // binary tree keeps one triangle per leaf and is collapsed into wide8 nodes by the same SAH-optimal DP as the SAH
+    // path (host side, like the driver's own post-build optimisation passes behind PREFER_FAST_TRACE).
+    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u);
     if(rc != VKRT_OK)
       return fail(rc, "LBVH build failed: %s", r.error.c_str());
-    s->accelNodes = r.nodes;
-    s->accelTris = r.tris;
-    s->accelShade = r.triShade;
-    s->dev.triShade = (const uint4*)r.triShade;
-    s->dev.nodes = (const float4*)r.nodes;
-    s->dev.tris = (const float4*)r.tris;
-    s->dev.triCount = r.triCount;
-    s->dev.rootRef = r.rootRef;
-    s->dev.layout = 0;
-    s->dev.stackCap = r.maxDepth + 2;
     s->info.triangle_count = r.triCount;
-    s->info.node_count = r.nodeCount;
-    s->info.max_depth = r.maxDepth;
-    s->info.sah_cost = r.sahCost;
-    s->info.node_bytes = (uint64_t)r.nodeCount * 64;
-    s->info.triangle_bytes = (uint64_t)r.triCount * 48;
+    s->dev.triCount = r.triCount;
+    if(wide && r.triCount > 0)
+    {
+      // download the binary tree (device layout == host layout of BuiltBvh) and the sorted triangle records
+      vkrt::BuiltBvh b2;
+      b2.nodes.resize((size_t)r.nodeCount * 16);
+      std::vector<float> trisHost((size_t)r.triCount * 12);
+      hipError_t e = hipSuccess;
+      if(r.nodeCount) e = hipMemcpy(b2.nodes.data(), r.nodes, b2.nodes.size() * 4, hipMemcpyDeviceToHost);
+      if(e == hipSuccess) e = hipMemcpy(trisHost.data(), r.tris, trisHost.size() * 4, hipMemcpyDeviceToHost);
+      (void)hipFree(r.nodes); (void)hipFree(r.tris); (void)hipFree(r.triShade);
+      if(e != hipSuccess)
+        return fail(VKRT_ERR_HIP, "LBVH download: %s", hipGetErrorString(e));
+      b2.rootRef = r.rootRef;
+      b2.maxDepth = r.maxDepth;
+      b2.triOrder.resize(r.triCount);
+      std::vector<vkrt::FlatTri> tris(r.triCount);
+      for(uint32_t k = 0; k < r.triCount; k++)
+      {
+        b2.triOrder[k] = k;
+        const float* t = &trisHost[(size_t)k * 12];
+        vkrt::FlatTri& ft = tris[k];
+        ft.v0[0] = t[0]; ft.v0[1] = t[1]; ft.v0[2] = t[2]; ft.e1[0] = t[3]; ft.e1[1] = t[4]; ft.e1[2] = t[5];
+        ft.e2[0] = t[6]; ft.e2[1] = t[7]; ft.e2[2] = t[8];
+        memcpy(&ft.gid, &t[9], 4); memcpy(&ft.inst, &t[10], 4); memcpy(&ft.prim, &t[11], 4);
+      }
+      vkrt::BuiltWide8 w8;
+      vkrt::collapse_wide8(b2, tris, w8);
+      std::vector<float> packed;
+      std::vector<uint32_t> shadeRec;
+      vkrt::pack_triangles(tris, w8.triOrder, packed);
+      vkrt::pack_tri_shade(tris, w8.triOrder, s->indices.data(), s->primMeshes.data(), s->nodes.data(), shadeRec);
+      HIP_TRY(hipMalloc(&s->accelNodes, std::max<size_t>(w8.nodes.size() * 4, 80)));
+      HIP_TRY(hipMalloc(&s->accelTris, std::max<size_t>(packed.size() * 4, 48)));
+      HIP_TRY(hipMalloc(&s->accelShade, std::max<size_t>(shadeRec.size() * 4, 16)));
+      HIP_TRY(hipMemcpy(s->accelNodes, w8.nodes.data(), w8.nodes.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->accelTris, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(s->accelShade, shadeRec.data(), shadeRec.size() * 4, hipMemcpyHostToDevice));
+      s->dev.nodes = (const float4*)s->accelNodes;
+      s->dev.tris = (const float4*)s->accelTris;
+      s->dev.triShade = (const uint4*)s->accelShade;
+      s->dev.layout = 1;
+      s->dev.rootRef = 0;
+      s->dev.stackCap = 2 * (w8.maxDepth + 3);
+      s->info.node_count = w8.nodeCount;
+      s->info.max_depth = w8.maxDepth;
+      s->info.sah_cost = w8.sahCost;
+      s->info.node_bytes = w8.nodes.size() * 4;
+      s->info.triangle_bytes = packed.size() * 4;
+    }
+    else
+    {
+      s->accelNodes = r.nodes;
+      s->accelTris = r.tris;
+      s->accelShade = r.triShade;
+      s->dev.triShade = (const uint4*)r.triShade;
+      s->dev.nodes = (const float4*)r.nodes;
+      s->dev.tris = (const float4*)r.tris;
+      s->dev.rootRef = r.rootRef;
+      s->dev.layout = 0;
+      s->dev.stackCap = r.maxDepth + 2;
+      s->info.node_count = r.nodeCount;
+      s->info.max_depth = r.maxDepth;
+      s->info.sah_cost = r.sahCost;
+      s->info.node_bytes = (uint64_t)r.nodeCount * 64;
+      s->info.triangle_bytes = (uint64_t)r.triCount * 48;
+    }
   }
   s->dev.stepLimit = 4u * (s->info.node_count + s->info.triangle_count) + 64u;
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
