@@ -45,7 +45,7 @@ VKRT_DEV void w8_begin(const DevScene& sc, W8State& S, f3 o, f3 d, float tmax, b
 }
 
 // returns true while the ray has more work
-template <bool COUNT>
+template <bool COUNT, bool ANYHIT>
 VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk, int stride, unsigned& nNodes, unsigned& nTris)
 {
   const float4* __restrict__ nodes = sc.nodes;
@@ -82,9 +82,13 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     const float asy = __uint_as_float(((ew >> 8) & 0xffu) << 23) * id.y;
     const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
     const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
-    const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox);
-    const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy);
-    const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz);
+    // Conservative pads folded into per-node constants: near planes move down, far planes up by 1e-6*|adj_origin|
+    // (absolute error of the fused form), and the far planes' scale carries the relative pad (1 + 2e-6 for
+    // positive t; a far plane behind the origin only matters when the box is missed anyway).
+    const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox) * 1.000002f;
+    const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy) * 1.000002f;
+    const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz) * 1.000002f;
+    const float fsx = asx * 1.000002f, fsy = asy * 1.000002f, fsz = asz * 1.000002f;
     // quantised planes, near/far by ray direction sign
     const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
     const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
@@ -92,24 +96,30 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     const unsigned nx[2] = {px ? lx0 : hx0, px ? lx1 : hx1}, fx[2] = {px ? hx0 : lx0, px ? hx1 : lx1};
     const unsigned ny[2] = {py ? ly0 : hy0, py ? ly1 : hy1}, fy[2] = {py ? hy0 : ly0, py ? hy1 : ly1};
     const unsigned nz[2] = {pz ? lz0 : hz0, pz ? lz1 : hz1}, fz[2] = {pz ? hz0 : lz0, pz ? hz1 : lz1};
-    const unsigned metaW[2] = {__float_as_uint(q1.z), __float_as_uint(q1.w)};
     const float bestT = S.bestT;
     unsigned hitmask = 0u;
 #pragma unroll
-    for(int i = 0; i < 8; i++)
+    for(int w = 0; w < 2; w++)
     {
-      const int w = i >> 2, k = i & 3;
-      const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), asx, fox);
-      const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), asy, foy);
-      const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), asz, foz);
-      const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT));
-      const unsigned meta = (metaW[w] >> (8 * k)) & 0xffu;
-      const bool inner = ((imask >> i) & 1u) != 0u;
-      const unsigned bits = inner ? 1u : (meta >> 5);
-      const unsigned bitIndex = inner ? (24u + ((unsigned)i ^ octinv)) : (meta & 31u);
-      if(tn <= tf * 1.000001f)
-        hitmask |= bits << bitIndex;
+      // four children at a time (one byte each): where the bits of a hit child go in the 32-bit hit mask.
+      // internal child: meta = 0x20 | (24 + slot) -> bit 24 + (slot ^ octinv), one bit;
+      // leaf child: meta = unary count << 5 | triangle offset -> `count` bits from bit `offset`.
+      const unsigned meta4 = __float_as_uint(w == 0 ? q1.z : q1.w);
+      const unsigned inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;         // bit 4 of a byte set <=> internal (24..31)
+      const unsigned innerMask4 = (inner4 >> 4) * 0x07u;                      // 0x07 per internal byte
+      const unsigned bitIndex4 = (meta4 ^ (octinv * 0x01010101u & innerMask4)) & 0x1f1f1f1fu;
+      const unsigned bits4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+      for(int k = 0; k < 4; k++)
+      {
+        const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), fsx, fox);
+        const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), fsy, foy);
+        const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), fsz, foz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * 1.000002f));
+        const unsigned piece = ((bits4 >> (8 * k)) & 0xffu) << ((bitIndex4 >> (8 * k)) & 0xffu);
+        hitmask |= (tn <= tf) ? piece : 0u;
+      }
     }
     G = make_uint2(__float_as_uint(q1.x), (hitmask & 0xff000000u) | imask);
     T = make_uint2(__float_as_uint(q1.y), hitmask & 0x00ffffffu);
@@ -131,7 +141,7 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     {
       if(t > tmin)
       {
-        if(S.anyHit)
+        if(ANYHIT)
         {
           if(t < S.tmax)
           {
@@ -169,9 +179,16 @@ VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float t
   W8State S;
   w8_begin(sc, S, o, d, tmax, anyHit);
   if(S.G.y != 0u)
-    while(w8_iterate<COUNT>(sc, S, tmin, stk, stride, nNodes, nTris))
-    {
-    }
+  {
+    if(anyHit)  // workgroup-uniform in the wavefront kernels: two specialised loops, no per-triangle branch
+      while(w8_iterate<COUNT, true>(sc, S, tmin, stk, stride, nNodes, nTris))
+      {
+      }
+    else
+      while(w8_iterate<COUNT, false>(sc, S, tmin, stk, stride, nNodes, nTris))
+      {
+      }
+  }
   hit.t = S.bestT; hit.u = S.bestU; hit.v = S.bestV; hit.slot = S.bestSlot;
 }
 

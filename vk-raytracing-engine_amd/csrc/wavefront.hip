@@ -308,7 +308,9 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse_refill(const TracePara
     }
     if(active)
     {
-      if(!w8_iterate<COUNT>(P.sc, S, 0.001f, stk, WF_BLOCK, nNodes, nTris))
+      const bool more = anyHit ? w8_iterate<COUNT, true>(P.sc, S, 0.001f, stk, WF_BLOCK, nNodes, nTris)
+                               : w8_iterate<COUNT, false>(P.sc, S, 0.001f, stk, WF_BLOCK, nNodes, nTris);
+      if(!more)
       {
         rec(B, pid)[2] = make_float4(S.bestT, S.bestU, S.bestV, __int_as_float(S.bestSlot));
         active = false;
