@@ -185,6 +185,31 @@ int vkrt_pathtrace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUni
                    const vkrt_trace_opts* opts, const vkrt_shard* shard,
                    float* rgba32f_device, void* hip_stream);
 
+/* ---- hybrid mode (reference rtMode == 0; SURVEY.md 8f row 1, BASELINE config 5) --------------------- */
+/* The four raster planes that raytraceHybrid.rgen reads (RtxBindings 1,3,4,6; host_device.h:51-63,
+ * attachments hello_vulkan.cpp:690-734).  Caller-owned device memory, rows of the shard stacked like the
+ * path-trace image. */
+typedef struct vkrt_gbuffer {
+  float* color;      /* rgba32f eOutImage : rgb = emission + un-shadowed direct light (frag_shader.frag:190-214), a = albedo.r */
+  float* position;   /* rgba32f ePosMap   : xyz = world position, w = albedo.g; cleared to (0,0,0,1)                    */
+  float* normal;     /* rgba32f eNormMap  : xyz = shading normal, w = albedo.b; cleared to (0,0,0,1)                     */
+  float* roughMetal; /* 2 floats/pixel eRoughMap: roughness, metalness after the rg16f round trip                        */
+} vkrt_gbuffer;
+/* Replaces the raster pass HelloVulkan::rasterizeGltf (hello_vulkan.cpp:583-615, vert_shader.vert,
+ * frag_shader.frag) by a primary ray cast per pixel centre evaluating the same shader math (textures at
+ * LOD 0).  lightsCount = PushConstantRaster.lightsCount. */
+int vkrt_gbuffer_raycast(vkrt_scene* scene, const float clearColor[4], int lightsCount, const GlobalUniforms* cam,
+                         const vkrt_shard* shard, const vkrt_gbuffer* out, void* hip_stream);
+/* Replaces HelloVulkan::raytraceRasterizedScene (hello_vulkan.cpp:1450-1473 = vkCmdTraceRaysKHR over
+ * raytraceHybrid.rgen): shadow / AO / GI per PushConstantRay.useShadows/useAO/useGI, accumulated into
+ * accum_rgba32f (eAccumMap; rgb = indirect light, a = visibility * (1 - ao)). */
+int vkrt_hybrid_trace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts,
+                      const vkrt_shard* shard, const vkrt_gbuffer* gbuffer, float* accum_rgba32f_device, void* hip_stream);
+/* Replaces drawPost's fragment stage (post.frag:36-58): hybrid composite main.rgb * rt.a + rt.rgb (rtMode 0) or
+ * pass-through (rtMode 1), then gamma 1/2.2 on all four channels.  n_pixels rgba32f device buffers. */
+int vkrt_post(int device, const PushConstantPost* pc, uint32_t n_pixels, const float* main_rgba32f, const float* rt_rgba32f,
+              float* out_rgba32f, void* hip_stream);
+
 /* ---- counters / timing ------------------------------------------------------------ */
 int vkrt_counters_reset(vkrt_scene* scene, void* hip_stream);
 int vkrt_counters_read(vkrt_scene* scene, vkrt_counters* out); /* synchronises the device */

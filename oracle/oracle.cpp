@@ -987,6 +987,275 @@ void rayGen(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms&
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Hybrid mode (BASELINE config 5).
+//   G-buffer: the reference rasterises vert_shader.vert / frag_shader.frag into 4 planes
+//   (hello_vulkan.cpp:583-615; attachments :690-734); with no raster hardware path from HIP the same
+//   planes come from a primary ray cast through each pixel centre evaluating the same shader math
+//   (cull mode NONE hello_vulkan.cpp:180; clear values main.cpp:482-487).  Textures are sampled at LOD 0
+//   (the raster path would use mips/anisotropy: documented difference).
+//   Hybrid ray-gen: raytraceHybrid.rgen:50-303.
+// ------------------------------------------------------------------------------------------
+// rg16f store of (roughness, metalness) (raytraceHybrid.rgen:20, hello_vulkan.cpp:704): float -> half (RNE) -> float
+inline float quantizeHalf(float f)
+{
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = x & 0x80000000u;
+  uint32_t ax = x & 0x7fffffffu;
+  if(ax >= 0x7f800000u)
+    return f;  // inf / nan unchanged
+  if(ax < 0x38800000u)
+  {  // below the smallest normal half (2^-14): quantise to multiples of 2^-24 (half subnormals), RNE
+    const uint32_t e = ax >> 23;
+    if(e < 101u)  // < 2^-26 -> rounds to zero (ties at 2^-25 go to even = 0)
+      ax = 0u;
+    else
+    {
+      const uint32_t mant = (ax & 0x7fffffu) | 0x800000u;
+      const uint32_t shift = 126u - e;             // 14..25
+      uint32_t q = mant >> shift;                   // units of 2^-24
+      const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+      if(rem > half || (rem == half && (q & 1u))) q++;
+      float r = (float)q * 5.9604644775390625e-8f;  // q * 2^-24, exact
+      memcpy(&ax, &r, 4);
+    }
+  }
+  else
+  {
+    const uint32_t rem = ax & 0x1fffu;
+    ax &= ~0x1fffu;
+    if(rem > 0x1000u || (rem == 0x1000u && (ax & 0x2000u))) ax += 0x2000u;
+    if(ax >= 0x47800000u) ax = 0x7f800000u;  // overflow to infinity
+  }
+  const uint32_t out = sign | ax;
+  float r;
+  memcpy(&r, &out, 4);
+  return r;
+}
+
+struct GbufPixel
+{
+  float color[4], position[4], normal[4], rough[2];
+};
+
+// vert_shader.vert:60-74 per vertex, barycentric interpolation (what the rasteriser does), frag_shader.frag:122-214
+void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount, const GlobalUniforms& uni, uint32_t x, uint32_t y, uint32_t W,
+                  uint32_t H, bool useBvh, GbufPixel& out, Counters& c)
+{
+  ShadeCtx cx{s, c};
+  for(int k = 0; k < 4; k++) out.color[k] = clearColor[k];            // main.cpp:483
+  out.position[0] = out.position[1] = out.position[2] = 0.0f; out.position[3] = 1.0f;   // main.cpp:485
+  out.normal[0] = out.normal[1] = out.normal[2] = 0.0f; out.normal[3] = 1.0f;           // main.cpp:486
+  out.rough[0] = out.rough[1] = 0.0f;                                                   // main.cpp:487
+  // primary ray through the pixel centre (same camera as raytrace.rgen:46-51 with jitter 0.5)
+  const float o4[4] = {0, 0, 0, 1};
+  float origin[4];
+  mat4MulVec4(uni.viewInverse, o4, origin);
+  const float inU = ((float)x + 0.5f) / (float)W, inV = ((float)y + 0.5f) / (float)H;
+  const float d4[4] = {inU * 2.0f - 1.0f, inV * 2.0f - 1.0f, 1, 1};
+  float target[4];
+  mat4MulVec4(uni.projInverse, d4, target);
+  const V3 tn = normalize(v3(target[0], target[1], target[2]));
+  const float t4[4] = {tn.x, tn.y, tn.z, 0};
+  float direction[4];
+  mat4MulVec4(uni.viewInverse, t4, direction);
+  const V3 org = v3(origin[0], origin[1], origin[2]), dir = v3(direction[0], direction[1], direction[2]);
+  c.rays_closest++;
+  const Hit h = useBvh ? closest_bvh(s, org, dir, 0.001f, 10000.0f, c) : closest_brute(s, org, dir, 0.001f, 10000.0f, c);
+  if(h.tri < 0)
+    return;
+  const Tri& tr = s.tris[h.tri];
+  const Instance& in = s.inst[tr.inst];
+  const vkrt_prim_mesh& pm = s.pm[in.primMesh];
+  const uint32_t base = pm.firstIndex + 3 * tr.prim;
+  const uint32_t vi[3] = {s.idx[base] + pm.vertexOffset, s.idx[base + 1] + pm.vertexOffset, s.idx[base + 2] + pm.vertexOffset};
+  const GltfPBRMaterial& mat = s.mats[(size_t)std::max(0, pm.materialIndex)];  // pcRaster.materialId (hello_vulkan.cpp:608)
+  const float bw[3] = {1.0f - h.u - h.v, h.u, h.v};
+  V3 wPos = v3(0.0f), wNrm = v3(0.0f), wTag = v3(0.0f), wBin = v3(0.0f);
+  float tu = 0.0f, tv = 0.0f;
+  for(int k = 0; k < 3; k++)
+  {
+    const uint32_t i = vi[k];
+    const V3 p = xformPoint(in, s.pos[i]);                       // modelMatrix * position
+    const V3 n = normalize(xformNormal(in, s.nrm[i]));           // mat3(inverseTranspose) * normal
+    V3 t = normalize(xformNormal(in, v3(s.tan4[4 * i], s.tan4[4 * i + 1], s.tan4[4 * i + 2])));
+    t = normalize(t - dot(t, n) * n);
+    const V3 b = cross(n, t) * s.tan4[4 * i + 3];
+    wPos = wPos + p * bw[k]; wNrm = wNrm + n * bw[k]; wTag = wTag + t * bw[k]; wBin = wBin + b * bw[k];
+    tu = tu + s.uv2[2 * i] * bw[k];
+    tv = tv + s.uv2[2 * i + 1] * bw[k];
+  }
+  const V3 viewDir = wPos - org;
+  // frag_shader.frag:96-119 getNormal
+  V3 N = normalize(wNrm);
+  if(mat.normalTexture > -1)
+  {
+    V3 T = normalize(wTag), B = normalize(wBin);
+    T = normalize(T - dot(T, N) * N);
+    B = normalize(B - dot(B, N) * N - dot(B, T) * T);
+    const V4 tx = sampleTex(s, mat.normalTexture, tu, tv, c);
+    V3 nrm = v3(tx.x, tx.y, tx.z) * 2.0f - v3(1.0f);
+    nrm = normalize(nrm);
+    nrm = normalize(T * nrm.x + B * nrm.y + N * nrm.z);
+    N = nrm;
+  }
+  const V3 baseColor = pbrGetBaseColor(cx, mat, tu, tv);
+  float metalness, roughness;
+  pbrGetMetallicRoughness(cx, mat, tu, tv, metalness, roughness);
+  const V3 albedo = (1.0f - metalness) * baseColor;
+  const V3 V = normalize(-viewDir);
+  V3 color = v3(0.0f);
+  V3 emittance = v3(mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]);
+  if(mat.emissiveTexture > -1)
+  {
+    const V4 tx = sampleTex(s, mat.emissiveTexture, tu, tv, c);
+    emittance = emittance * v3(tx.x, tx.y, tx.z);
+  }
+  for(int i = 0; i < lightsCount; i++)  // frag_shader.frag:193-213 (every light, no shadow test)
+  {
+    const GltfLight& light = s.lights[(size_t)i];
+    const V3 lp = v3(light.position[0], light.position[1], light.position[2]);
+    V3 L = normalize(lp - wPos);
+    V3 lightIntensity = v3(light.color[0], light.color[1], light.color[2]) * light.intensity;
+    if(light.type == 0)
+    {
+      const V3 lDir = lp - wPos;
+      const float d = length(lDir);
+      lightIntensity = lightIntensity / (d * d);
+    }
+    else
+      L = normalize(lp);
+    const V3 Hh = normalize(L + V);
+    const float cosTheta = glsl_max(dot(L, N), 0.0f);
+    if(cosTheta > 0.0f)
+      color = color + computePBR_BRDF(cx, N, V, L, Hh, mat, tu, tv) * lightIntensity * cosTheta;
+  }
+  const V3 oc = emittance + color;
+  out.color[0] = oc.x; out.color[1] = oc.y; out.color[2] = oc.z; out.color[3] = albedo.x;
+  out.position[0] = wPos.x; out.position[1] = wPos.y; out.position[2] = wPos.z; out.position[3] = albedo.y;
+  out.normal[0] = N.x; out.normal[1] = N.y; out.normal[2] = N.z; out.normal[3] = albedo.z;
+  out.rough[0] = quantizeHalf(roughness);
+  out.rough[1] = quantizeHalf(metalness);
+}
+
+// raytraceHybrid.rgen:50-303 for one pixel; accum = imageAccum texel (in/out)
+void hybridPixel(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms& uni, uint32_t seedArg, uint32_t flags, uint32_t x, uint32_t y,
+                 uint32_t W, bool useBvh, const GbufPixel& g, float* accum, Counters& c)
+{
+  ShadeCtx cx{s, c};
+  c.pixels++;
+  Payload prd;
+  memset(&prd, 0, sizeof(prd));
+  const uint32_t index = (flags & VKRT_TRACE_SEED_INDEX_ROW_MAJOR) ? (y * W + x) : (y * x + x);  // rgen:55
+  prd.seed = tea(index, seedArg);
+  float color[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+  const V3 worldPos = v3(g.position[0], g.position[1], g.position[2]);
+  const V3 worldNrm = v3(g.normal[0], g.normal[1], g.normal[2]);
+  auto accumulateFrames = [&]() {  // rgen:36-48
+    if(pc.frame > 0)
+    {
+      const float a = 1.0f / (float)(pc.frame + 1);
+      for(int k = 0; k < 4; k++) accum[k] = accum[k] * (1.0f - a) + color[k] * a;
+    }
+    else
+      for(int k = 0; k < 4; k++) accum[k] = color[k];
+  };
+  if(worldPos.x == 0.0f && worldPos.y == 0.0f && worldPos.z == 0.0f && worldNrm.x == 0.0f && worldNrm.y == 0.0f && worldNrm.z == 0.0f)
+  {
+    accumulateFrames();
+    return;
+  }
+  const V3 albedo = v3(g.color[3], g.position[3], g.normal[3]);
+  const float roughness = g.rough[0], metalness = g.rough[1];
+  auto anyHit = [&](V3 o, V3 d, float tmin, float tmax) {
+    c.rays_shadow++;
+    return useBvh ? any_bvh(s, o, d, tmin, tmax, c) : any_brute(s, o, d, tmin, tmax, c);
+  };
+  if(pc.useShadows == 1)  // rgen:81-131
+  {
+    float visibility = 1.0f;
+    const int random_index = (int)(rnd(prd.seed) * (float)pc.lightsCount);
+    const GltfLight& light = s.lights[(size_t)random_index];
+    const V3 lightDir = v3(light.position[0], light.position[1], light.position[2]) - worldPos;
+    const float lightDistance = length(lightDir);
+    const V3 L = normalize(lightDir);
+    if(dot(L, worldNrm) < 0.0f)
+      visibility = 0.0f;
+    else if(anyHit(worldPos, L, 0.1f, lightDistance - 0.1f))
+      visibility = 0.0f;
+    visibility = glsl_max(visibility, 0.01f);
+    color[3] *= visibility;
+  }
+  if(pc.useAO == 1)  // rgen:134-169
+  {
+    float ao = 0.0f;
+    V3 tangent, binormal;
+    createCoordinateSystem(worldNrm, tangent, binormal);
+    const float weightAo = 1.0f / 4;
+    for(int i = 0; i < 4; i++)
+    {
+      const V3 rayDir = normalize(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
+      if(anyHit(worldPos, rayDir, 0.1f, 2.0f))
+        ao += weightAo;
+    }
+    color[3] *= (1.0f - ao);
+  }
+  if(pc.useGI == 1)  // rgen:172-282 (the NRD packing at :273-281 is inert and not restated)
+  {
+    V3 hitValues = v3(0.0f);
+    const float tMin = 0.001f, tMax = 10000.0f;
+    V3 direction, curWeight;
+    const float ratio = metalness * (1.0f - roughness);
+    if(ratio < 0.8f)
+    {
+      prd.isSpecular = false;
+      V3 tangent, binormal;
+      createCoordinateSystem(worldNrm, tangent, binormal);
+      direction = normalize(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
+      curWeight = albedo;
+    }
+    else
+    {
+      prd.isSpecular = true;
+      const float o4[4] = {0, 0, 0, 1};
+      float cam[4];
+      mat4MulVec4(uni.viewInverse, o4, cam);
+      const V3 V = normalize(v3(cam[0], cam[1], cam[2]) - worldPos);
+      direction = normalize(glsl_reflect(-V, worldNrm));
+      curWeight = v3(1.0f);
+    }
+    prd.hitValue = v3(0.0f);
+    prd.rayOrigin = worldPos;
+    prd.rayDirection = direction;
+    prd.depth = 1;
+    prd.weight = v3(0.0f);
+    V3 hitValue = v3(0.0f);
+    for(; prd.depth < (uint32_t)pc.depth; prd.depth++)
+    {
+      c.rays_closest++;
+      const V3 rd = prd.rayDirection;
+      const Hit h = useBvh ? closest_bvh(s, prd.rayOrigin, rd, tMin, tMax, c) : closest_brute(s, prd.rayOrigin, rd, tMin, tMax, c);
+      if(h.tri >= 0)
+        closestHitShader(cx, pc, h, rd, prd);
+      else
+        missShader(pc, prd);
+      bool shadowHit = false;
+      if(!prd.isSpecular && prd.depth != 100)
+        shadowHit = anyHit(prd.rayOrigin, prd.shadowRayDir, tMin, prd.lightDist - 0.1f);
+      if(!shadowHit)
+      {
+        const V3 q = prd.hitValue * curWeight;
+        hitValue = hitValue + v3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
+      }
+      curWeight = curWeight * prd.weight;
+    }
+    hitValues = hitValues + hitValue;
+    color[0] = hitValues.x; color[1] = hitValues.y; color[2] = hitValues.z;
+  }
+  accumulateFrames();
+}
+
 thread_local char g_err[256] = "";
 
 }  // namespace
@@ -1274,6 +1543,106 @@ void orc_camera_ray(const GlobalUniforms* uni, uint32_t x, uint32_t y, uint32_t 
   out6[0] = origin[0]; out6[1] = origin[1]; out6[2] = origin[2];
   out6[3] = direction[0]; out6[4] = direction[1]; out6[5] = direction[2];
 }
+
+/* G-buffer of rows[0..nrows): planes color/position/normal (nrows x W x 4 floats) and rough (nrows x W x 2). */
+int orc_gbuffer_rows(const orc_scene* s, const float* clearColor, int lightsCount, const GlobalUniforms* cam, uint32_t full_w, uint32_t full_h,
+                     const uint32_t* rows, uint32_t nrows, float* color, float* position, float* normal, float* rough, int use_bvh, int threads)
+{
+  if(lightsCount < 0 || (uint32_t)lightsCount > s->lights.size())
+  {
+    snprintf(g_err, sizeof g_err, "lightsCount out of range");
+    return 1;
+  }
+  int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  if(nt < 1) nt = 1;
+  std::atomic<uint32_t> next{0};
+  auto work = [&]() {
+    Counters c;
+    for(;;)
+    {
+      const uint32_t r = next.fetch_add(1);
+      if(r >= nrows) break;
+      for(uint32_t x = 0; x < full_w; x++)
+      {
+        GbufPixel g;
+        gbufferPixel(*s, clearColor, lightsCount, *cam, x, rows[r], full_w, full_h, use_bvh != 0, g, c);
+        const size_t p = (size_t)r * full_w + x;
+        memcpy(color + 4 * p, g.color, 16); memcpy(position + 4 * p, g.position, 16); memcpy(normal + 4 * p, g.normal, 16);
+        memcpy(rough + 2 * p, g.rough, 8);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for(int t = 1; t < nt; t++) th.emplace_back(work);
+  work();
+  for(auto& t : th) t.join();
+  return 0;
+}
+
+/* raytraceHybrid.rgen over rows[0..nrows) given the G-buffer planes of those rows; accum (nrows x W x 4) is in/out. */
+int orc_hybrid_rows(const orc_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, uint32_t seed, uint32_t flags, uint32_t full_w,
+                    uint32_t full_h, const uint32_t* rows, uint32_t nrows, const float* color, const float* position, const float* normal,
+                    const float* rough, float* accum, int use_bvh, int threads, uint64_t* counters)
+{
+  (void)full_h;
+  if(pc->lightsCount < 0 || (uint32_t)pc->lightsCount > s->lights.size())
+  {
+    snprintf(g_err, sizeof g_err, "lightsCount out of range");
+    return 1;
+  }
+  int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  if(nt < 1) nt = 1;
+  std::atomic<uint32_t> next{0};
+  std::vector<Counters> cs((size_t)nt);
+  auto work = [&](int tid) {
+    Counters& c = cs[(size_t)tid];
+    for(;;)
+    {
+      const uint32_t r = next.fetch_add(1);
+      if(r >= nrows) break;
+      for(uint32_t x = 0; x < full_w; x++)
+      {
+        const size_t p = (size_t)r * full_w + x;
+        GbufPixel g;
+        memcpy(g.color, color + 4 * p, 16); memcpy(g.position, position + 4 * p, 16); memcpy(g.normal, normal + 4 * p, 16);
+        memcpy(g.rough, rough + 2 * p, 8);
+        hybridPixel(*s, *pc, *cam, seed, flags, x, rows[r], full_w, use_bvh != 0, g, accum + 4 * p, c);
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for(int t = 1; t < nt; t++) th.emplace_back(work, t);
+  work(0);
+  for(auto& t : th) t.join();
+  if(counters)
+  {
+    Counters tot;
+    for(auto& c : cs) tot.add(c);
+    counters[0] = tot.rays_closest; counters[1] = tot.rays_shadow; counters[2] = tot.hits; counters[3] = tot.diffuse_hits;
+    counters[4] = tot.tex_taps; counters[5] = tot.pixels; counters[6] = tot.nodes_visited; counters[7] = tot.tris_tested;
+  }
+  return 0;
+}
+
+/* post.frag:36-58 composite + gamma for n pixels (rtMode 0 = hybrid composite, 1 = path tracer pass-through). */
+void orc_post(int rtMode, int viewAccumulated, int useGI, uint32_t n, const float* mainImg, const float* rtImg, float* out)
+{
+  const float gamma = 1.0f / 2.2f;
+  for(uint32_t i = 0; i < n; i++)
+  {
+    float m[4] = {mainImg[4 * i], mainImg[4 * i + 1], mainImg[4 * i + 2], mainImg[4 * i + 3]};
+    if(rtMode == 0)
+    {
+      const float* r = rtImg + 4 * (size_t)i;
+      if(viewAccumulated == 0) { m[0] = m[0] * r[3] + r[0]; m[1] = m[1] * r[3] + r[1]; m[2] = m[2] * r[3] + r[2]; m[3] = 1.0f; }
+      else if(useGI == 1) { m[0] = r[0] * r[3]; m[1] = r[1] * r[3]; m[2] = r[2] * r[3]; }
+      else { m[0] = m[1] = m[2] = r[3]; }
+    }
+    for(int k = 0; k < 4; k++) out[4 * (size_t)i + k] = powf(m[k], gamma);
+  }
+}
+
+float orc_quantize_half(float f) { return quantizeHalf(f); }
 
 /* Bilinear sampler spot check: uv = float[2n] -> rgba float[4n] from texture texIndex. */
 void orc_sample_texture(const orc_scene* s, int texIndex, uint32_t n, const float* uv, float* rgba)

@@ -50,6 +50,15 @@ def lib():
         L.orc_eval_math.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_eval_shade.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_camera_ray.argtypes = [P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+        L.orc_gbuffer_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_gbuffer_rows.restype = C.c_int
+        L.orc_hybrid_rows.argtypes = [C.c_void_p, P(abi.PushConstantRay), P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_hybrid_rows.restype = C.c_int
+        L.orc_post.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_quantize_half.argtypes = [C.c_float]
+        L.orc_quantize_half.restype = C.c_float
         L.orc_sample_texture.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -125,6 +134,31 @@ class OracleScene:
                              t.ctypes.data, u.ctypes.data, v.ctypes.data, gid.ctypes.data, cnt.ctypes.data)
         return t, u, v, gid, {"nodes_visited": int(cnt[6]), "tris_tested": int(cnt[7])}
 
+    def gbuffer(self, cam, width, height, lights_count, clear_color=(1.0, 1.0, 1.0, 1.0), rows=None, use_bvh=True, threads=0):
+        rows = np.arange(height, dtype=np.uint32) if rows is None else np.ascontiguousarray(rows, np.uint32)
+        n = rows.shape[0]
+        g = {"color": np.zeros((n, width, 4), np.float32), "position": np.zeros((n, width, 4), np.float32),
+             "normal": np.zeros((n, width, 4), np.float32), "roughMetal": np.zeros((n, width, 2), np.float32)}
+        cc = np.asarray(clear_color, np.float32)
+        rc = lib().orc_gbuffer_rows(self._h, cc.ctypes.data, lights_count, C.byref(cam), width, height, rows.ctypes.data, n, g["color"].ctypes.data,
+                                    g["position"].ctypes.data, g["normal"].ctypes.data, g["roughMetal"].ctypes.data, 1 if use_bvh else 0, threads)
+        if rc != 0:
+            raise RuntimeError("orc_gbuffer_rows: " + lib().orc_last_error().decode())
+        return g
+
+    def hybrid(self, pc, cam, width, height, g, seed=0, flags=0, rows=None, accum=None, use_bvh=True, threads=0):
+        rows = np.arange(height, dtype=np.uint32) if rows is None else np.ascontiguousarray(rows, np.uint32)
+        n = rows.shape[0]
+        if accum is None:
+            accum = np.zeros((n, width, 4), np.float32)
+        cnt = np.zeros(8, np.uint64)
+        rc = lib().orc_hybrid_rows(self._h, C.byref(pc), C.byref(cam), seed, flags, width, height, rows.ctypes.data, n, g["color"].ctypes.data,
+                                   g["position"].ctypes.data, g["normal"].ctypes.data, g["roughMetal"].ctypes.data, accum.ctypes.data,
+                                   1 if use_bvh else 0, threads, cnt.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("orc_hybrid_rows: " + lib().orc_last_error().decode())
+        return accum, dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
+
     def sample_texture(self, tex_index, uv):
         uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         out = np.zeros((uv.shape[0], 4), np.float32)
@@ -164,6 +198,18 @@ def camera_ray(cam, x, y, W, H, jx=0.5, jy=0.5):
     out = np.zeros(6, np.float32)
     lib().orc_camera_ray(C.byref(cam), x, y, W, H, jx, jy, out.ctypes.data)
     return out[:3], out[3:]
+
+
+def post(main_img, rt_img, rt_mode=0, view_accumulated=0, use_gi=0):
+    m = np.ascontiguousarray(main_img, np.float32)
+    r = np.ascontiguousarray(rt_img if rt_img is not None else main_img, np.float32)
+    out = np.zeros_like(m)
+    lib().orc_post(rt_mode, view_accumulated, use_gi, m.size // 4, m.ctypes.data, r.ctypes.data, out.ctypes.data)
+    return out
+
+
+def quantize_half(x):
+    return np.array([lib().orc_quantize_half(float(v)) for v in np.asarray(x, np.float32).ravel()], np.float32).reshape(np.shape(x))
 
 
 def algorithmic_bytes(counters, frame_gt0=False):

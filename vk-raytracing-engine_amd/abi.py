@@ -139,6 +139,14 @@ class AccelInfo(C.Structure):
     ]
 
 
+class Gbuffer(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("position", C.c_void_p), ("normal", C.c_void_p), ("roughMetal", C.c_void_p)]
+
+
+class PushConstantPost(C.Structure):
+    _fields_ = [("aspectRatio", c_f), ("rtMode", c_i), ("viewAccumulated", c_i), ("useGI", c_i)]
+
+
 class TraceTiming(C.Structure):
     _fields_ = [("total_ms", c_f), ("traverse_ms", c_f), ("traverse_launches", c_u), ("mode", c_u)]
 
@@ -169,6 +177,9 @@ VKRT_SYMBOLS = [
     "vkrt_accel_get_info",
     "vkrt_shard_rows",
     "vkrt_pathtrace",
+    "vkrt_gbuffer_raycast",
+    "vkrt_hybrid_trace",
+    "vkrt_post",
     "vkrt_counters_reset",
     "vkrt_counters_read",
     "vkrt_last_trace_ms",
@@ -198,6 +209,12 @@ def declare_vkrt(lib):
         C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), C.c_void_p, C.c_void_p,
     ]
     lib.vkrt_pathtrace.restype = C.c_int
+    lib.vkrt_gbuffer_raycast.argtypes = [C.c_void_p, P(c_f * 4), C.c_int, P(GlobalUniforms), P(Shard), P(Gbuffer), C.c_void_p]
+    lib.vkrt_gbuffer_raycast.restype = C.c_int
+    lib.vkrt_hybrid_trace.argtypes = [C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), P(Gbuffer), C.c_void_p, C.c_void_p]
+    lib.vkrt_hybrid_trace.restype = C.c_int
+    lib.vkrt_post.argtypes = [C.c_int, P(PushConstantPost), c_u, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vkrt_post.restype = C.c_int
     lib.vkrt_counters_reset.argtypes = [C.c_void_p, C.c_void_p]
     lib.vkrt_counters_reset.restype = C.c_int
     lib.vkrt_counters_read.argtypes = [C.c_void_p, P(Counters)]

@@ -1,0 +1,400 @@
+// hybrid.hip -- hybrid mode of the reference (BASELINE config 5):
+//   k_gbuffer  stands in for the raster pass HelloVulkan::rasterizeGltf (hello_vulkan.cpp:583-615) with
+//              vert_shader.vert:60-74 / frag_shader.frag:122-214: there is no raster path from HIP, so the
+//              four planes raytraceHybrid.rgen reads are produced by a primary ray through each pixel centre
+//              evaluating the same per-vertex and per-fragment math (cull NONE :180, clear values main.cpp:482-487).
+//   k_hybrid   raytraceHybrid.rgen:50-303 (1 shadow ray, 4 AO rays, optional GI path reusing the path tracer's
+//              closest-hit / miss shaders), accumulating into the rgba32f accumulation image (:36-48).
+//   k_post     post.frag:36-58 composite (raster.rgb * rt.a + rt.rgb) and gamma 1/2.2.
+// One thread per pixel; traversal and shading are the path tracer's (traverse*.h, shade.h).
+#include <hip/hip_runtime.h>
+
+#include "device_math.h"
+#include "device_scene.h"
+#include "kernels.h"
+#include "rgen.h"
+#include "shade.h"
+#include "traverse.h"
+#include "traverse_wide.h"
+
+#define HY_BLOCK 256
+
+// rg16f store of (roughness, metalness): float -> half (RNE) -> float, integer-exact (same routine as the oracle)
+VKRT_DEV float quantizeHalf(float f)
+{
+  const uint32_t x = __float_as_uint(f);
+  const uint32_t sign = x & 0x80000000u;
+  uint32_t ax = x & 0x7fffffffu;
+  if(ax >= 0x7f800000u)
+    return f;
+  if(ax < 0x38800000u)
+  {
+    const uint32_t e = ax >> 23;
+    if(e < 101u)
+      ax = 0u;
+    else
+    {
+      const uint32_t mant = (ax & 0x7fffffu) | 0x800000u;
+      const uint32_t shift = 126u - e;
+      uint32_t q = mant >> shift;
+      const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+      if(rem > half || (rem == half && (q & 1u))) q++;
+      ax = __float_as_uint((float)q * 5.9604644775390625e-8f);
+    }
+  }
+  else
+  {
+    const uint32_t rem = ax & 0x1fffu;
+    ax &= ~0x1fffu;
+    if(rem > 0x1000u || (rem == 0x1000u && (ax & 0x2000u))) ax += 0x2000u;
+    if(ax >= 0x47800000u) ax = 0x7f800000u;
+  }
+  return __uint_as_float(sign | ax);
+}
+
+struct HybridParams
+{
+  TraceParams T;      // scene, pc, camera, launch geometry (image pointer unused)
+  float4* color;      // eOutImage  rgba32f
+  float4* position;   // ePosMap    rgba32f
+  float4* normal;     // eNormMap   rgba32f
+  float2* rough;      // eRoughMap  (rg16f-quantised values held as floats)
+  float4* accum;      // eAccumMap  rgba32f
+  float clearColor[4];
+  int lightsCount;
+};
+
+VKRT_DEV bool pixelOf(const TraceParams& P, uint32_t& x, uint32_t& y, uint32_t& lrow)
+{
+  const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;  // tile-major, as in the path tracer
+  if(w >= P.tileCount * 64u)
+    return false;
+  const unsigned tile = w >> 6, inTile = w & 63u;
+  x = (tile % P.tilesX) * 8u + (inTile & 7u);
+  lrow = (tile / P.tilesX) * 8u + (inTile >> 3);
+  if(x >= P.fullW || lrow >= P.localRows)
+    return false;
+  y = globalRow(P, lrow);
+  return y < P.fullH;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
+{
+  extern __shared__ int lds_stack[];
+  const TraceParams& P = H.T;
+  const DevScene& sc = P.sc;
+  uint32_t x, y, lrow;
+  unsigned nClosest = 0, nNodes = 0, nTris = 0;
+  ShadeStats st;
+  st.hits = 0; st.diffuse = 0; st.taps = 0;
+  if(pixelOf(P, x, y, lrow))
+  {
+    const size_t p = (size_t)lrow * P.fullW + x;
+    float4 oColor = make_float4(H.clearColor[0], H.clearColor[1], H.clearColor[2], H.clearColor[3]);
+    float4 oPos = make_float4(0.0f, 0.0f, 0.0f, 1.0f), oNrm = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    float2 oRough = make_float2(0.0f, 0.0f);
+    float origin[4], target[4], direction[4];
+    mat4MulVec4(P.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f, origin);
+    const float inU = ((float)x + 0.5f) / (float)P.fullW, inV = ((float)y + 0.5f) / (float)P.fullH;
+    mat4MulVec4(P.projInverse, inU * 2.0f - 1.0f, inV * 2.0f - 1.0f, 1.0f, 1.0f, target);
+    const f3 tn = normalize3(mk3(target[0], target[1], target[2]));
+    mat4MulVec4(P.viewInverse, tn.x, tn.y, tn.z, 0.0f, direction);
+    const f3 org = mk3(origin[0], origin[1], origin[2]), dir = mk3(direction[0], direction[1], direction[2]);
+    RayHit hit;
+    nClosest = 1;
+    traverse_any<false, WIDE>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+    if(hit.slot >= 0)
+    {
+      const float4 recq = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
+      const DevInstance in = sc.instances[(uint32_t)__float_as_int(recq.z)];
+      const uint4 ts = sc.triShade[hit.slot];
+      const uint32_t vi[3] = {ts.x, ts.y, ts.z};
+      const float4* mq = (const float4*)&sc.materials[ts.w];
+      const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
+      GltfPBRMaterial mat;
+      mat.pbrBaseColorFactor[0] = m0.x; mat.pbrBaseColorFactor[1] = m0.y; mat.pbrBaseColorFactor[2] = m0.z; mat.pbrBaseColorFactor[3] = m0.w;
+      mat.pbrBaseColorTexture = __float_as_int(m1.x); mat.metallicFactor = m1.y; mat.roughnessFactor = m1.z;
+      mat.metallicRoughnessTexture = __float_as_int(m1.w);
+      mat.normalTexture = __float_as_int(m2.x); mat.emissiveFactor[0] = m2.y; mat.emissiveFactor[1] = m2.z; mat.emissiveFactor[2] = m2.w;
+      mat.emissiveTexture = __float_as_int(m3.x);
+      const float bw[3] = {1.0f - hit.u - hit.v, hit.u, hit.v};
+      f3 wPos = mk3(0.0f), wNrm = mk3(0.0f), wTag = mk3(0.0f), wBin = mk3(0.0f);
+      float tu = 0.0f, tv = 0.0f;
+#pragma unroll
+      for(int k = 0; k < 3; k++)  // vert_shader.vert:60-74 per vertex, then the rasteriser's barycentric interpolation
+      {
+        const float4 a = sc.vertexPN[2 * vi[k]], b = sc.vertexPN[2 * vi[k] + 1];
+        const float4 tq = ((const float4*)sc.tangents)[vi[k]];
+        const f3 pw = xformPoint(in, mk3(a.x, a.y, a.z));
+        const f3 n = normalize3(xformNormal(in, mk3(a.w, b.x, b.y)));
+        f3 t = normalize3(xformNormal(in, mk3(tq.x, tq.y, tq.z)));
+        t = normalize3(t - dot3(t, n) * n);
+        const f3 bn = cross3(n, t) * tq.w;
+        wPos = wPos + pw * bw[k]; wNrm = wNrm + n * bw[k]; wTag = wTag + t * bw[k]; wBin = wBin + bn * bw[k];
+        tu = tu + b.z * bw[k];
+        tv = tv + b.w * bw[k];
+      }
+      const f3 viewDir = wPos - org;
+      f3 N = normalize3(wNrm);  // frag_shader.frag:96-119
+      if(mat.normalTexture > -1)
+      {
+        f3 T = normalize3(wTag), B = normalize3(wBin);
+        T = normalize3(T - dot3(T, N) * N);
+        B = normalize3(B - dot3(B, N) * N - dot3(B, T) * T);
+        const f4 tx = sampleTex(sc, mat.normalTexture, tu, tv, st);
+        f3 nrm = mk3(tx.x, tx.y, tx.z) * 2.0f - mk3(1.0f);
+        nrm = normalize3(nrm);
+        nrm = normalize3(T * nrm.x + B * nrm.y + N * nrm.z);
+        N = nrm;
+      }
+      const f3 baseColor = pbrGetBaseColor(sc, mat, tu, tv, st);
+      float metalness, roughness;
+      pbrGetMetallicRoughness(sc, mat, tu, tv, metalness, roughness, st);
+      const f3 albedo = (1.0f - metalness) * baseColor;
+      const f3 V = normalize3(-viewDir);
+      f3 color = mk3(0.0f);
+      f3 emittance = mk3(mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]);
+      if(mat.emissiveTexture > -1)
+      {
+        const f4 tx = sampleTex(sc, mat.emissiveTexture, tu, tv, st);
+        emittance = emittance * mk3(tx.x, tx.y, tx.z);
+      }
+      const unsigned retap = (mat.pbrBaseColorTexture > -1 ? 1u : 0u) + (mat.metallicRoughnessTexture > -1 ? 1u : 0u);
+      for(int i = 0; i < H.lightsCount; i++)  // frag_shader.frag:193-213
+      {
+        const float4* lq = (const float4*)&sc.lights[i];
+        const float4 l0 = lq[0], l1 = lq[1];
+        const f3 lp = mk3(l0.x, l0.y, l0.z);
+        f3 L = normalize3(lp - wPos);
+        f3 lightIntensity = mk3(l0.w, l1.x, l1.y) * l1.z;
+        if(__float_as_int(l1.w) == 0)
+        {
+          const f3 lDir = lp - wPos;
+          const float d = length3(lDir);
+          lightIntensity = lightIntensity / (d * d);
+        }
+        else
+          L = normalize3(lp);
+        const f3 Hh = normalize3(L + V);
+        const float cosTheta = glsl_max(dot3(L, N), 0.0f);
+        if(cosTheta > 0.0f)
+        {
+          st.taps += retap;
+          color = color + computePBR_BRDF(N, V, L, Hh, baseColor, metalness, roughness) * lightIntensity * cosTheta;
+        }
+      }
+      const f3 oc = emittance + color;
+      oColor = make_float4(oc.x, oc.y, oc.z, albedo.x);
+      oPos = make_float4(wPos.x, wPos.y, wPos.z, albedo.y);
+      oNrm = make_float4(N.x, N.y, N.z, albedo.z);
+      oRough = make_float2(quantizeHalf(roughness), quantizeHalf(metalness));
+    }
+    H.color[p] = oColor; H.position[p] = oPos; H.normal[p] = oNrm; H.rough[p] = oRough;
+  }
+  __shared__ unsigned long long red[8 * (HY_BLOCK / 64)];
+  const unsigned vals[5] = {nClosest, 0, 0, 0, st.taps};
+  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 5, red);
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
+{
+  extern __shared__ int lds_stack[];
+  const TraceParams& P = H.T;
+  const DevScene& sc = P.sc;
+  uint32_t x, y, lrow;
+  unsigned nClosest = 0, nShadow = 0, nPixels = 0, nNodes = 0, nTris = 0;
+  ShadeStats st;
+  st.hits = 0; st.diffuse = 0; st.taps = 0;
+  if(pixelOf(P, x, y, lrow))
+  {
+    nPixels = 1;
+    const size_t p = (size_t)lrow * P.fullW + x;
+    Payload prd;
+    prd.seed = tea((P.flags & 1u) ? (y * P.fullW + x) : (y * x + x), P.seed);  // rgen:55
+    prd.isSpecular = false; prd.lightDist = 0.0f; prd.shadowRayDir = mk3(0.0f); prd.depth = 0;
+    prd.hitValue = mk3(0.0f); prd.weight = mk3(0.0f); prd.rayOrigin = mk3(0.0f); prd.rayDirection = mk3(0.0f);
+    float4 color = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    const float4 pixelImg = H.color[p], pixelPos = H.position[p], pixelNorm = H.normal[p];
+    const float2 rm = H.rough[p];
+    const f3 worldPos = mk3(pixelPos.x, pixelPos.y, pixelPos.z), worldNrm = mk3(pixelNorm.x, pixelNorm.y, pixelNorm.z);
+    const bool shaded = !(worldPos.x == 0.0f && worldPos.y == 0.0f && worldPos.z == 0.0f && worldNrm.x == 0.0f && worldNrm.y == 0.0f &&
+                          worldNrm.z == 0.0f);  // rgen:67
+    if(shaded)
+    {
+      const f3 albedo = mk3(pixelImg.w, pixelPos.w, pixelNorm.w);
+      const float roughness = rm.x, metalness = rm.y;
+      RayHit hit;
+      if(P.pc.useShadows == 1)  // rgen:81-131
+      {
+        float visibility = 1.0f;
+        const int random_index = (int)(rnd(prd.seed) * (float)P.pc.lightsCount);
+        const float4 l0 = ((const float4*)&sc.lights[random_index])[0];
+        const f3 lightDir = mk3(l0.x, l0.y, l0.z) - worldPos;
+        const float lightDistance = length3(lightDir);
+        const f3 L = normalize3(lightDir);
+        if(dot3(L, worldNrm) < 0.0f)
+          visibility = 0.0f;
+        else
+        {
+          nShadow++;
+          traverse_any<false, WIDE>(sc, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+          if(hit.slot >= 0)
+            visibility = 0.0f;
+        }
+        visibility = glsl_max(visibility, 0.01f);
+        color.w *= visibility;
+      }
+      if(P.pc.useAO == 1)  // rgen:134-169
+      {
+        float ao = 0.0f;
+        f3 tangent, binormal;
+        createCoordinateSystem(worldNrm, tangent, binormal);
+        const float weightAo = 1.0f / 4;
+        for(int i = 0; i < 4; i++)
+        {
+          const f3 rayDir = normalize3(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
+          nShadow++;
+          traverse_any<false, WIDE>(sc, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+          if(hit.slot >= 0)
+            ao += weightAo;
+        }
+        color.w *= (1.0f - ao);
+      }
+      if(P.pc.useGI == 1)  // rgen:172-282
+      {
+        f3 direction, curWeight;
+        const float ratio = metalness * (1.0f - roughness);
+        if(ratio < 0.8f)
+        {
+          prd.isSpecular = false;
+          f3 tangent, binormal;
+          createCoordinateSystem(worldNrm, tangent, binormal);
+          direction = normalize3(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
+          curWeight = albedo;
+        }
+        else
+        {
+          prd.isSpecular = true;
+          float cam[4];
+          mat4MulVec4(P.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f, cam);
+          const f3 V = normalize3(mk3(cam[0], cam[1], cam[2]) - worldPos);
+          direction = normalize3(glsl_reflect(-V, worldNrm));
+          curWeight = mk3(1.0f);
+        }
+        prd.hitValue = mk3(0.0f);
+        prd.rayOrigin = worldPos;
+        prd.rayDirection = direction;
+        prd.depth = 1;
+        prd.weight = mk3(0.0f);
+        f3 hitValue = mk3(0.0f);
+        for(; prd.depth < (uint32_t)P.pc.depth; prd.depth++)
+        {
+          nClosest++;
+          const f3 rd = prd.rayDirection;
+          traverse_any<false, WIDE>(sc, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+          if(hit.slot >= 0)
+            closestHitShader(sc, P.pc, hit, rd, prd, st);
+          else
+            missShader(P.pc, prd);
+          bool shadowHit = false;
+          if(!prd.isSpecular && prd.depth != 100u)
+          {
+            nShadow++;
+            traverse_any<false, WIDE>(sc, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, (int)threadIdx.x, HY_BLOCK,
+                                      hit, nNodes, nTris);
+            shadowHit = hit.slot >= 0;
+          }
+          if(!shadowHit)
+          {
+            const f3 q = prd.hitValue * curWeight;
+            hitValue = hitValue + mk3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
+          }
+          curWeight = curWeight * prd.weight;
+        }
+        color.x = hitValue.x; color.y = hitValue.y; color.z = hitValue.z;
+      }
+    }
+    // accumulateFrames, rgen:36-48 (all four channels)
+    if(P.pc.frame > 0)
+    {
+      const float a = 1.0f / (float)(P.pc.frame + 1);
+      const float4 old = H.accum[p];
+      H.accum[p] = make_float4(old.x * (1.0f - a) + color.x * a, old.y * (1.0f - a) + color.y * a, old.z * (1.0f - a) + color.z * a,
+                               old.w * (1.0f - a) + color.w * a);
+    }
+    else
+      H.accum[p] = color;
+  }
+  __shared__ unsigned long long red[8 * (HY_BLOCK / 64)];
+  const unsigned vals[6] = {nClosest, nShadow, st.hits, st.diffuse, st.taps, nPixels};
+  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 6, red);
+}
+
+// post.frag:36-58
+__global__ void k_post(int rtMode, int viewAccumulated, int useGI, unsigned n, const float4* mainImg, const float4* rtImg, float4* out)
+{
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  float4 m = mainImg[i];
+  if(rtMode == 0)
+  {
+    const float4 r = rtImg[i];
+    if(viewAccumulated == 0)
+      m = make_float4(m.x * r.w + r.x, m.y * r.w + r.y, m.z * r.w + r.z, 1.0f);
+    else if(useGI == 1)
+    {
+      m.x = r.x * r.w; m.y = r.y * r.w; m.z = r.z * r.w;
+    }
+    else
+    {
+      m.x = r.w; m.y = r.w; m.z = r.w;
+    }
+  }
+  const float gamma = 1.0f / 2.2f;
+  out[i] = make_float4(powf(m.x, gamma), powf(m.y, gamma), powf(m.z, gamma), powf(m.w, gamma));
+}
+
+hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], int lightsCount, float* color, float* position, float* normal,
+                               float* rough, hipStream_t stream)
+{
+  HybridParams H;
+  H.T = P;
+  H.color = (float4*)color; H.position = (float4*)position; H.normal = (float4*)normal; H.rough = (float2*)rough; H.accum = nullptr;
+  for(int k = 0; k < 4; k++) H.clearColor[k] = clearColor[k];
+  H.lightsCount = lightsCount;
+  const unsigned blocks = (P.tileCount * 64u + HY_BLOCK - 1) / HY_BLOCK;
+  const size_t lds = (size_t)P.sc.stackCap * HY_BLOCK * sizeof(int);
+  if(P.sc.layout == 1u)
+    hipLaunchKernelGGL(k_gbuffer<true>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  else
+    hipLaunchKernelGGL(k_gbuffer<false>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  return hipGetLastError();
+}
+
+hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const float* position, const float* normal, const float* rough, float* accum,
+                              hipStream_t stream)
+{
+  HybridParams H;
+  H.T = P;
+  H.color = (float4*)color; H.position = (float4*)position; H.normal = (float4*)normal; H.rough = (float2*)rough; H.accum = (float4*)accum;
+  for(int k = 0; k < 4; k++) H.clearColor[k] = 0.0f;
+  H.lightsCount = P.pc.lightsCount;
+  const unsigned blocks = (P.tileCount * 64u + HY_BLOCK - 1) / HY_BLOCK;
+  const size_t lds = (size_t)P.sc.stackCap * HY_BLOCK * sizeof(int);
+  if(P.sc.layout == 1u)
+    hipLaunchKernelGGL(k_hybrid<true>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  else
+    hipLaunchKernelGGL(k_hybrid<false>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  return hipGetLastError();
+}
+
+hipError_t vkrt_launch_post(int rtMode, int viewAccumulated, int useGI, unsigned n, const float* mainImg, const float* rtImg, float* out,
+                            hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_post, dim3((n + 255) / 256), dim3(256), 0, stream, rtMode, viewAccumulated, useGI, n, (const float4*)mainImg,
+                     (const float4*)rtImg, (float4*)out);
+  return hipGetLastError();
+}

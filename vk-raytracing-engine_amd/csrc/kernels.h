@@ -20,3 +20,11 @@ struct WfTiming
 size_t     vkrt_wf_state_bytes(uint32_t pathCapacity);
 void       vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B);
 hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing);
+
+// hybrid mode (hybrid.hip)
+hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], int lightsCount, float* color, float* position, float* normal,
+                               float* rough, hipStream_t stream);
+hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const float* position, const float* normal, const float* rough, float* accum,
+                              hipStream_t stream);
+hipError_t vkrt_launch_post(int rtMode, int viewAccumulated, int useGI, unsigned n, const float* mainImg, const float* rtImg, float* out,
+                            hipStream_t stream);

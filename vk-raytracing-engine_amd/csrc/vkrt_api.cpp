@@ -617,6 +617,99 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   return VKRT_OK;
 }
 
+namespace {
+// launch geometry shared by the hybrid entry points (same shard semantics as vkrt_pathtrace)
+int fillParams(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
+               TraceParams& P)
+{
+  if(!s->built)
+    return fail(VKRT_ERR_NOT_BUILT, "acceleration structure not built");
+  if(shard->full_width == 0 || shard->full_height == 0)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "empty launch size");
+  if(shard->shard_count > 1 && (shard->strip_rows == 0 || shard->shard_index >= shard->shard_count))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "bad shard");
+  memset(&P, 0, sizeof P);
+  P.sc = s->dev;
+  if(pc) P.pc = *pc;
+  memcpy(P.viewInverse, cam->viewInverse.m, sizeof P.viewInverse);
+  memcpy(P.projInverse, cam->projInverse.m, sizeof P.projInverse);
+  P.seed = opts ? opts->seed : 0u;
+  P.flags = opts ? opts->flags : 0u;
+  P.fullW = shard->full_width;
+  P.fullH = shard->full_height;
+  const bool sharded = shard->shard_count > 1;
+  P.stripRows = sharded ? shard->strip_rows : 0u;
+  P.shardCount = sharded ? shard->shard_count : 1u;
+  P.shardIndex = sharded ? shard->shard_index : 0u;
+  P.localRows = vkrt_shard_rows(shard);
+  P.counters = s->counters;
+  P.tilesX = (P.fullW + 7) / 8;
+  const uint64_t tiles = (uint64_t)P.tilesX * ((P.localRows + 7) / 8);
+  if(tiles * 64 >= 0xFFFFFFFFull)
+    return fail(VKRT_ERR_UNSUPPORTED, "launch too large");
+  P.tileCount = (uint32_t)tiles;
+  return VKRT_OK;
+}
+}  // namespace
+
+int vkrt_gbuffer_raycast(vkrt_scene* s, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const vkrt_shard* shard,
+                         const vkrt_gbuffer* out, void* hip_stream)
+{
+  if(!s || !clearColor || !cam || !shard || !out || !out->color || !out->position || !out->normal || !out->roughMetal)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(lightsCount < 0 || (uint32_t)lightsCount > s->lightCount)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "lightsCount %d outside [0,%u]", lightsCount, s->lightCount);
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  TraceParams P;
+  if((rc = fillParams(s, nullptr, cam, nullptr, shard, P)) != VKRT_OK)
+    return rc;
+  if(P.localRows == 0)
+    return VKRT_OK;
+  HIP_TRY(vkrt_launch_gbuffer(P, clearColor, lightsCount, out->color, out->position, out->normal, out->roughMetal, (hipStream_t)hip_stream));
+  return VKRT_OK;
+}
+
+int vkrt_hybrid_trace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
+                      const vkrt_gbuffer* g, float* accum, void* hip_stream)
+{
+  if(!s || !pc || !cam || !shard || !g || !accum || !g->color || !g->position || !g->normal || !g->roughMetal)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(pc->lightsCount < 0 || (uint32_t)pc->lightsCount > s->lightCount)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "PushConstantRay.lightsCount %d outside [0,%u]", pc->lightsCount, s->lightCount);
+  if(pc->depth < 0 || pc->depth > 99)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "depth out of range");
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  TraceParams P;
+  if((rc = fillParams(s, pc, cam, opts, shard, P)) != VKRT_OK)
+    return rc;
+  if(P.localRows == 0)
+    return VKRT_OK;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  HIP_TRY(hipEventRecord(s->evStart, stream));
+  HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, stream));
+  HIP_TRY(hipEventRecord(s->evStop, stream));
+  s->timed = true;
+  s->wfTimed = false;
+  return VKRT_OK;
+}
+
+int vkrt_post(int device, const PushConstantPost* pc, uint32_t n, const float* mainImg, const float* rtImg, float* out, void* hip_stream)
+{
+  if(!pc || !mainImg || !out || (pc->rtMode == 0 && !rtImg))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(vkrt_device_count() <= 0)
+    return fail(VKRT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  HIP_TRY(hipSetDevice(device));
+  if(n == 0)
+    return VKRT_OK;
+  HIP_TRY(vkrt_launch_post(pc->rtMode, pc->viewAccumulated, pc->useGI, n, mainImg, rtImg, out, (hipStream_t)hip_stream));
+  return VKRT_OK;
+}
+
 int vkrt_counters_reset(vkrt_scene* s, void* hip_stream)
 {
   if(!s)

@@ -94,6 +94,51 @@ class Renderer:
                                        C.c_void_p(image.data_ptr()), C.c_void_p(stream.cuda_stream)), "vkrt_pathtrace")
         return image
 
+    # ---- hybrid mode (reference rtMode == 0) ---------------------------------------------------------
+    def gbuffer_raycast(self, cam, width, height, lights_count=None, clear_color=(1.0, 1.0, 1.0, 1.0), shard=None, stream=None):
+        """Stand-in for rasterizeGltf: returns dict of torch CUDA planes color/position/normal [rows,W,4], roughMetal [rows,W,2]."""
+        import torch
+
+        shard = shard or whole_image_shard(width, height)
+        rows = self.shard_rows(shard)
+        dev = f"cuda:{self.device}"
+        g = {"color": torch.zeros((rows, width, 4), dtype=torch.float32, device=dev), "position": torch.zeros((rows, width, 4), dtype=torch.float32, device=dev),
+             "normal": torch.zeros((rows, width, 4), dtype=torch.float32, device=dev), "roughMetal": torch.zeros((rows, width, 2), dtype=torch.float32, device=dev)}
+        stream = stream or torch.cuda.current_stream(g["color"].device)
+        gb = abi.Gbuffer(*(g[k].data_ptr() for k in ("color", "position", "normal", "roughMetal")))
+        cc = (C.c_float * 4)(*clear_color)
+        n = self.lights_count if lights_count is None else lights_count
+        _check(self.lib.vkrt_gbuffer_raycast(self._h, C.byref(cc), n, C.byref(cam), C.byref(shard), C.byref(gb), C.c_void_p(stream.cuda_stream)),
+               "vkrt_gbuffer_raycast")
+        return g
+
+    def hybrid_trace(self, pc, cam, width, height, gbuffer, seed=0, flags=0, shard=None, accum=None, stream=None):
+        """raytraceHybrid.rgen: accum [rows,W,4] (in/out when pc.frame > 0)."""
+        import torch
+
+        shard = shard or whole_image_shard(width, height)
+        rows = self.shard_rows(shard)
+        if accum is None:
+            accum = torch.zeros((rows, width, 4), dtype=torch.float32, device=f"cuda:{self.device}")
+        stream = stream or torch.cuda.current_stream(accum.device)
+        gb = abi.Gbuffer(*(gbuffer[k].data_ptr() for k in ("color", "position", "normal", "roughMetal")))
+        opts = abi.TraceOpts(seed & 0xFFFFFFFF, flags)
+        _check(self.lib.vkrt_hybrid_trace(self._h, C.byref(pc), C.byref(cam), C.byref(opts), C.byref(shard), C.byref(gb),
+                                          C.c_void_p(accum.data_ptr()), C.c_void_p(stream.cuda_stream)), "vkrt_hybrid_trace")
+        return accum
+
+    def post(self, main_img, rt_img=None, rt_mode=0, view_accumulated=0, use_gi=0, stream=None):
+        """post.frag composite + gamma; returns a new [.,.,4] tensor."""
+        import torch
+
+        out = torch.empty_like(main_img)
+        stream = stream or torch.cuda.current_stream(main_img.device)
+        pcp = abi.PushConstantPost(1.0, rt_mode, view_accumulated, use_gi)
+        _check(self.lib.vkrt_post(self.device, C.byref(pcp), main_img.numel() // 4, C.c_void_p(main_img.data_ptr()),
+                                  C.c_void_p(rt_img.data_ptr()) if rt_img is not None else None, C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(stream.cuda_stream)), "vkrt_post")
+        return out
+
     def reset_counters(self, stream=None):
         _check(self.lib.vkrt_counters_reset(self._h, C.c_void_p(stream.cuda_stream) if stream is not None else None),
                "vkrt_counters_reset")
