@@ -151,6 +151,9 @@ typedef struct vkrt_counters {
   uint64_t pixels;         /* rgen invocations                                  */
   uint64_t nodes_visited;  /* only with VKRT_TRACE_COUNT_TRAVERSAL              */
   uint64_t tris_tested;    /* only with VKRT_TRACE_COUNT_TRAVERSAL              */
+  uint64_t wave_node_steps; /* COUNT_TRAVERSAL, wide8 layout: node steps per wavefront (one per 64 lanes);
+                              nodes_visited / (64 * wave_node_steps) = lane efficiency of the node phase */
+  uint64_t wave_tri_steps;  /* same for the triangle phase                        */
 } vkrt_counters;
 
 typedef struct vkrt_accel_info {

@@ -238,3 +238,43 @@ def test_cli_renders_config_json(tmp_path, small_atrium):
     pfm = (tmp_path / "out.pfm").read_bytes()
     assert pfm.startswith(b"PF\n96 54\n-1.0\n") and len(pfm) == len(b"PF\n96 54\n-1.0\n") + 96 * 54 * 12
     assert (tmp_path / "out.ppm").read_bytes().startswith(b"P6\n96 54\n255\n")
+
+
+@pytest.mark.gpu
+def test_cli_hybrid_mode_matches_oracle(tmp_path, small_atrium):
+    """config.json "mode": "hybrid" -> rasterizeGltf -> raytraceRasterizedScene -> drawPost (reference main.cpp:510-561)."""
+    import subprocess
+
+    import atrium
+    import gltf_export
+    import gltf_flatten
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+
+    path = str(tmp_path / "scene.gltf")
+    gltf_export.export_gltf(small_atrium, path)
+    W, H = 96, 54
+    cam = atrium.DEFAULT_CAMERA
+    cfg = {"scenes": ["scene.gltf"], "scene": 0, "vsync": False, "width": W, "height": H, "depth": 3, "frames": 2, "mode": "hybrid", "useGI": True,
+           "seed": 5, "camera": {"eye": list(cam["eye"]), "center": list(cam["center"]), "up": list(cam["up"]), "fov": cam["fov"]},
+           "output": str(tmp_path / "hy")}
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    exe = os.path.join(ROOT, "vk-raytracing-engine_amd", "vkrt_render")
+    p = subprocess.run([exe, "--config", str(tmp_path / "config.json")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    head = b"PF\n%d %d\n-1.0\n" % (W, H)
+    pfm = (tmp_path / "hy.pfm").read_bytes()
+    img = np.frombuffer(pfm[len(head):], np.float32).reshape(H, W, 3)[::-1]  # PFM rows run bottom-up
+
+    flat = gltf_flatten.load_gltf(path)
+    orc = oracle_py.OracleScene(flat)
+    u = host_py.global_uniforms(width=W, height=H, **cam)
+    g = orc.gbuffer(u, W, H, lights_count=len(flat.lights), clear_color=(1, 1, 1, 1))
+    acc = np.zeros((H, W, 4), np.float32)
+    for f in range(2):
+        pc = make_push_constants(samples=1, depth=3, frame=f, lights_count=len(flat.lights))
+        pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+        acc, _ = orc.hybrid(pc, u, W, H, g, seed=5 + f, accum=acc)  # seedPerFrame default
+    want = g["color"][..., :3] * acc[..., 3:4] + acc[..., :3]
+    bad = np.abs(img - want) > 1e-4 * (1 + np.abs(want))
+    assert bad.any(axis=-1).mean() < 2e-3

@@ -25,7 +25,10 @@ for spp, depth in ((1, 1), (1, 8), (4, 8)):
     r.pathtrace(pc, cam, W, H, seed=1, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL, image=img)
     cc = r.counters()
     work = {"nodes_per_ray": round(cc["nodes_visited"] / rays, 2), "tris_per_ray": round(cc["tris_tested"] / rays, 2),
-            "shadow_frac": round(cc["rays_shadow"] / rays, 3)}
+            "shadow_frac": round(cc["rays_shadow"] / rays, 3),
+            "node_lane_eff": round(cc["nodes_visited"] / max(64 * cc["wave_node_steps"], 1), 3),
+            "tri_lane_eff": round(cc["tris_tested"] / max(64 * cc["wave_tri_steps"], 1), 3),
+            "wave_node_steps": cc["wave_node_steps"], "wave_tri_steps": cc["wave_tri_steps"]}
     print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("VKRT_")}, "spp": spp, "depth": depth, "rays": rays,
                       "total_ms": round(t["total_ms"], 3), "traverse_ms": round(t["traverse_ms"], 3), "launches": t["traverse_launches"],
                       "Mrays_s_total": round(rays / t["total_ms"] / 1e3, 1), "Mrays_s_traverse": round(rays / max(t["traverse_ms"], 1e-9) / 1e3, 1), "mode": t["mode"], **work}))

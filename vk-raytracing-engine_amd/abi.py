@@ -120,6 +120,8 @@ class Counters(C.Structure):
         ("pixels", c_u64),
         ("nodes_visited", c_u64),
         ("tris_tested", c_u64),
+        ("wave_node_steps", c_u64),
+        ("wave_tri_steps", c_u64),
     ]
 
     def as_dict(self):

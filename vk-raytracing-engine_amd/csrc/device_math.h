@@ -12,8 +12,17 @@
 
 VKRT_DEV unsigned lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Block-reduce up to 8 per-lane counters through LDS and add them to this block's counter slot with
-// one atomic per non-zero counter.  `dst` = &counters->v[blockIdx.x % SLOTS][0]; red = 8*(blockDim/64) u64 of LDS.
+#define VKRT_COUNTER_STRIDE 16  // u64 per counter slot (10 used; two 64-byte lines)
+
+// Traversal work tallies (only maintained by COUNT instantiations).  waveNodeSteps / waveTriSteps are bumped by one
+// lane per wavefront per node step / triangle step, so nodes / (64 * waveNodeSteps) is the lane efficiency of that phase.
+struct TravCount
+{
+  unsigned nodes = 0, tris = 0, waveNodeSteps = 0, waveTriSteps = 0;
+};
+
+// Block-reduce up to 10 per-lane counters through LDS and add them to this block's counter slot with
+// one atomic per non-zero counter.  `dst` = &counters->v[blockIdx.x % SLOTS][0]; red = VKRT_COUNTER_STRIDE*(blockDim/64) u64 of LDS.
 VKRT_DEV void blockAddCounters(unsigned long long* dst, const unsigned* vals, int n, unsigned long long* red)
 {
   const unsigned lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -24,14 +33,14 @@ VKRT_DEV void blockAddCounters(unsigned long long* dst, const unsigned* vals, in
     for(int off = 32; off > 0; off >>= 1)
       x += __shfl_xor(x, off);
     if(lane == 0)
-      red[wave * 8 + k] = x;
+      red[wave * VKRT_COUNTER_STRIDE + k] = x;
   }
   __syncthreads();
   if(threadIdx.x < (unsigned)n)
   {
     unsigned long long t = 0;
     for(unsigned w = 0; w < nw; w++)
-      t += red[w * 8 + threadIdx.x];
+      t += red[w * VKRT_COUNTER_STRIDE + threadIdx.x];
     if(t != 0ull)
       atomicAdd(&dst[threadIdx.x], t);
   }

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/vkrt_host_device.h"
+#include "device_math.h"
 
 // One TLAS instance (hello_vulkan.cpp:1035-1043): object->world rows + inverse 3x3 + primMesh.
 struct DevInstance
@@ -81,15 +82,18 @@ struct DevScene
   uint32_t stackCap;          // traversal stack: 4-byte LDS words per lane
   uint32_t layout;            // 0 = BVH2 (64-B nodes), 1 = wide8 (80-B compressed nodes)
   uint32_t stepLimit;         // traversal step bound (termination safety net)
+  uint32_t triThreshold;      // wide8: lanes with pending triangles needed before a wave tests them (0 = test at once)
 };
 
-// Counter storage: 64 slots of 8 counters (one 64-byte line each, order of vkrt_counters).  A workgroup
+// Counter storage: 64 slots of 10 counters (padded to two 64-byte lines, order of vkrt_counters).  A workgroup
 // adds its block-reduced totals to slot (blockIdx % 64), so same-address atomic serialisation is
 // 64x lower than with one set of counters; vkrt_counters_read sums the slots.
+#define VKRT_W8_MAX_POSTPONED 4  // parked triangle groups per lane (traverse_wide.h)
+
 #define VKRT_COUNTER_SLOTS 64
 struct DevCounters
 {
-  unsigned long long v[VKRT_COUNTER_SLOTS][8];
+  unsigned long long v[VKRT_COUNTER_SLOTS][VKRT_COUNTER_STRIDE];
 };
 
 struct TraceParams

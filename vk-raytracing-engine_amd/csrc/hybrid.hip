@@ -85,7 +85,8 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
   const TraceParams& P = H.T;
   const DevScene& sc = P.sc;
   uint32_t x, y, lrow;
-  unsigned nClosest = 0, nNodes = 0, nTris = 0;
+  unsigned nClosest = 0;
+  TravCount tc;
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
   if(pixelOf(P, x, y, lrow))
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
     const f3 org = mk3(origin[0], origin[1], origin[2]), dir = mk3(direction[0], direction[1], direction[2]);
     RayHit hit;
     nClosest = 1;
-    traverse_any<false, WIDE>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+    traverse_any<false, WIDE>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
     if(hit.slot >= 0)
     {
       const float4 recq = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
     }
     H.color[p] = oColor; H.position[p] = oPos; H.normal[p] = oNrm; H.rough[p] = oRough;
   }
-  __shared__ unsigned long long red[8 * (HY_BLOCK / 64)];
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (HY_BLOCK / 64)];
   const unsigned vals[5] = {nClosest, 0, 0, 0, st.taps};
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 5, red);
 }
@@ -204,7 +205,8 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
   const TraceParams& P = H.T;
   const DevScene& sc = P.sc;
   uint32_t x, y, lrow;
-  unsigned nClosest = 0, nShadow = 0, nPixels = 0, nNodes = 0, nTris = 0;
+  unsigned nClosest = 0, nShadow = 0, nPixels = 0;
+  TravCount tc;
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
   if(pixelOf(P, x, y, lrow))
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
         else
         {
           nShadow++;
-          traverse_any<false, WIDE>(sc, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+          traverse_any<false, WIDE>(sc, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
           if(hit.slot >= 0)
             visibility = 0.0f;
         }
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
         {
           const f3 rayDir = normalize3(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
           nShadow++;
-          traverse_any<false, WIDE>(sc, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+          traverse_any<false, WIDE>(sc, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
           if(hit.slot >= 0)
             ao += weightAo;
         }
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
         {
           nClosest++;
           const f3 rd = prd.rayDirection;
-          traverse_any<false, WIDE>(sc, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, nNodes, nTris);
+          traverse_any<false, WIDE>(sc, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
           if(hit.slot >= 0)
             closestHitShader(sc, P.pc, hit, rd, prd, st);
           else
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
           {
             nShadow++;
             traverse_any<false, WIDE>(sc, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, (int)threadIdx.x, HY_BLOCK,
-                                      hit, nNodes, nTris);
+                                      hit, tc);
             shadowHit = hit.slot >= 0;
           }
           if(!shadowHit)
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
     else
       H.accum[p] = color;
   }
-  __shared__ unsigned long long red[8 * (HY_BLOCK / 64)];
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (HY_BLOCK / 64)];
   const unsigned vals[6] = {nClosest, nShadow, st.hits, st.diffuse, st.taps, nPixels};
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 6, red);
 }

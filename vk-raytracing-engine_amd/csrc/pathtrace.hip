@@ -32,7 +32,8 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
   LaneState L;
   bool active = false;
   bool exhausted = false;  // wave-uniform: work counter ran out
-  unsigned nClosest = 0, nShadow = 0, nPixels = 0, nNodes = 0, nTris = 0;
+  unsigned nClosest = 0, nShadow = 0, nPixels = 0;
+  TravCount tc;
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
   const uint32_t totalWork = P.tileCount * 64u;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
         nClosest++;
       }
       RayHit hit;
-      traverse<COUNT>(P.sc, o, d, tmin, tmax, shadow, stk, VKRT_BLOCK, hit, nNodes, nTris);
+      traverse<COUNT>(P.sc, o, d, tmin, tmax, shadow, stk, VKRT_BLOCK, hit, tc);
 
       bool shadowHit = false;
       bool accumulate = true;
@@ -121,9 +122,9 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
   }
 
   // ---- counters: block reduce, one atomic per counter per block ------------------------------------
-  __shared__ unsigned long long red[8 * (VKRT_BLOCK / 64)];
-  const unsigned vals[8] = {nClosest, nShadow, st.hits, st.diffuse, st.taps, nPixels, nNodes, nTris};
-  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 8 : 6, red);
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (VKRT_BLOCK / 64)];
+  const unsigned vals[10] = {nClosest, nShadow, st.hits, st.diffuse, st.taps, nPixels, tc.nodes, tc.tris, tc.waveNodeSteps, tc.waveTriSteps};
+  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 10 : 6, red);
 }
 
 // ---- debug / test kernels --------------------------------------------------------------------------
@@ -135,13 +136,13 @@ __global__ __launch_bounds__(VKRT_BLOCK) void k_trace_rays(DevScene sc, unsigned
   if(i >= n)
     return;
   RayHit hit;
-  unsigned a = 0, b = 0;
+  TravCount tc;
   if(sc.layout == 1u)
     traverse_any<false, true>(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax, anyHit != 0,
-                              lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, a, b);
+                              lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
   else
     traverse_any<false, false>(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax, anyHit != 0,
-                               lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, a, b);
+                               lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
   if(anyHit)
   {
     gid[i] = hit.slot >= 0 ? 0 : -1;

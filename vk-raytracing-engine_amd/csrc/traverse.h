@@ -64,7 +64,7 @@ VKRT_DEV bool tri_test(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t, float& u, floa
 // stk: this lane's LDS stack column (entry k at stk[k * stride]).
 template <bool COUNT>
 VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* stk, int stride, RayHit& hit,
-                       unsigned& nNodes, unsigned& nTris)
+                       TravCount& tc)
 {
   const f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   const float4* __restrict__ nodes = sc.nodes;
@@ -90,7 +90,7 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
       const float4 q1 = nodes[cur * VKRT_NODE_QUADS + 1];
       const float4 q2 = nodes[cur * VKRT_NODE_QUADS + 2];
       const float4 q3 = nodes[cur * VKRT_NODE_QUADS + 3];
-      if(COUNT) nNodes++;
+      if(COUNT) tc.nodes++;
       float tn0, tn1;
       const bool h0 = box_test(o, id, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmin, bestT, tn0);
       const bool h1 = box_test(o, id, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmin, bestT, tn1);
@@ -134,7 +134,7 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
         const float4 a = tris[s * VKRT_TRI_QUADS + 0];
         const float4 b = tris[s * VKRT_TRI_QUADS + 1];
         const float4 c = tris[s * VKRT_TRI_QUADS + 2];
-        if(COUNT) nTris++;
+        if(COUNT) tc.tris++;
         float t, u, v;
         if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
         {

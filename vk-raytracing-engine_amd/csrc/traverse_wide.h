@@ -44,9 +44,74 @@ VKRT_DEV void w8_begin(const DevScene& sc, W8State& S, f3 o, f3 d, float tmax, b
   S.anyHit = anyHit;
 }
 
+// Test the 8 children of wide node `child` against the ray: G = (child base, hit internal children | imask),
+// T = (triangle base, 24-bit mask of the leaf triangles whose boxes the ray touched).
+template <bool COUNT>
+VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child, f3 o, f3 id, unsigned octinv, bool px, bool py, bool pz, float tmin,
+                               float bestT_in, uint2& G, uint2& T, TravCount& tc)
+{
+  const float4 q0 = nodes[child * VKRT_WNODE_QUADS + 0];
+  const float4 q1 = nodes[child * VKRT_WNODE_QUADS + 1];
+  const float4 q2 = nodes[child * VKRT_WNODE_QUADS + 2];
+  const float4 q3 = nodes[child * VKRT_WNODE_QUADS + 3];
+  const float4 q4 = nodes[child * VKRT_WNODE_QUADS + 4];
+  if(COUNT)
+  {
+    tc.nodes++;
+    if((int)lane_id() == __ffsll((long long)__ballot(1)) - 1) tc.waveNodeSteps++;
+  }
+  const unsigned ew = __float_as_uint(q0.w);
+  const unsigned imask = ew >> 24;
+  const float asx = __uint_as_float((ew & 0xffu) << 23) * id.x;
+  const float asy = __uint_as_float(((ew >> 8) & 0xffu) << 23) * id.y;
+  const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
+  const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
+  // Conservative pads folded into per-node constants: near planes move down, far planes up by 1e-6*|adj_origin|
+  // (absolute error of the fused form), and the far planes' scale carries the relative pad (1 + 2e-6 for
+  // positive t; a far plane behind the origin only matters when the box is missed anyway).
+  const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox) * 1.000002f;
+  const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy) * 1.000002f;
+  const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz) * 1.000002f;
+  const float fsx = asx * 1.000002f, fsy = asy * 1.000002f, fsz = asz * 1.000002f;
+  // quantised planes, near/far by ray direction sign
+  const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
+  const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
+  const unsigned hy0 = __float_as_uint(q4.x), hy1 = __float_as_uint(q4.y), hz0 = __float_as_uint(q4.z), hz1 = __float_as_uint(q4.w);
+  const unsigned nx[2] = {px ? lx0 : hx0, px ? lx1 : hx1}, fx[2] = {px ? hx0 : lx0, px ? hx1 : lx1};
+  const unsigned ny[2] = {py ? ly0 : hy0, py ? ly1 : hy1}, fy[2] = {py ? hy0 : ly0, py ? hy1 : ly1};
+  const unsigned nz[2] = {pz ? lz0 : hz0, pz ? lz1 : hz1}, fz[2] = {pz ? hz0 : lz0, pz ? hz1 : lz1};
+  const float bestT = bestT_in;
+  unsigned hitmask = 0u;
+#pragma unroll
+  for(int w = 0; w < 2; w++)
+  {
+    // four children at a time (one byte each): where the bits of a hit child go in the 32-bit hit mask.
+    // internal child: meta = 0x20 | (24 + slot) -> bit 24 + (slot ^ octinv), one bit;
+    // leaf child: meta = unary count << 5 | triangle offset -> `count` bits from bit `offset`.
+    const unsigned meta4 = __float_as_uint(w == 0 ? q1.z : q1.w);
+    const unsigned inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;         // bit 4 of a byte set <=> internal (24..31)
+    const unsigned innerMask4 = (inner4 >> 4) * 0x07u;                      // 0x07 per internal byte
+    const unsigned bitIndex4 = (meta4 ^ (octinv * 0x01010101u & innerMask4)) & 0x1f1f1f1fu;
+    const unsigned bits4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+    for(int k = 0; k < 4; k++)
+    {
+      const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), fsx, fox);
+      const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), fsy, foy);
+      const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), fsz, foz);
+      const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * 1.000002f));
+      const unsigned piece = ((bits4 >> (8 * k)) & 0xffu) << ((bitIndex4 >> (8 * k)) & 0xffu);
+      hitmask |= (tn <= tf) ? piece : 0u;
+    }
+  }
+  G = make_uint2(__float_as_uint(q1.x), (hitmask & 0xff000000u) | imask);
+  T = make_uint2(__float_as_uint(q1.y), hitmask & 0x00ffffffu);
+}
+
 // returns true while the ray has more work
 template <bool COUNT, bool ANYHIT>
-VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk, int stride, unsigned& nNodes, unsigned& nTris)
+VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk, int stride, TravCount& tc)
 {
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
@@ -70,59 +135,7 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     }
     if(--S.steps == 0u)
       return false;
-    const float4 q0 = nodes[child * VKRT_WNODE_QUADS + 0];
-    const float4 q1 = nodes[child * VKRT_WNODE_QUADS + 1];
-    const float4 q2 = nodes[child * VKRT_WNODE_QUADS + 2];
-    const float4 q3 = nodes[child * VKRT_WNODE_QUADS + 3];
-    const float4 q4 = nodes[child * VKRT_WNODE_QUADS + 4];
-    if(COUNT) nNodes++;
-    const unsigned ew = __float_as_uint(q0.w);
-    const unsigned imask = ew >> 24;
-    const float asx = __uint_as_float((ew & 0xffu) << 23) * id.x;
-    const float asy = __uint_as_float(((ew >> 8) & 0xffu) << 23) * id.y;
-    const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
-    const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
-    // Conservative pads folded into per-node constants: near planes move down, far planes up by 1e-6*|adj_origin|
-    // (absolute error of the fused form), and the far planes' scale carries the relative pad (1 + 2e-6 for
-    // positive t; a far plane behind the origin only matters when the box is missed anyway).
-    const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox) * 1.000002f;
-    const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy) * 1.000002f;
-    const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz) * 1.000002f;
-    const float fsx = asx * 1.000002f, fsy = asy * 1.000002f, fsz = asz * 1.000002f;
-    // quantised planes, near/far by ray direction sign
-    const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
-    const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
-    const unsigned hy0 = __float_as_uint(q4.x), hy1 = __float_as_uint(q4.y), hz0 = __float_as_uint(q4.z), hz1 = __float_as_uint(q4.w);
-    const unsigned nx[2] = {px ? lx0 : hx0, px ? lx1 : hx1}, fx[2] = {px ? hx0 : lx0, px ? hx1 : lx1};
-    const unsigned ny[2] = {py ? ly0 : hy0, py ? ly1 : hy1}, fy[2] = {py ? hy0 : ly0, py ? hy1 : ly1};
-    const unsigned nz[2] = {pz ? lz0 : hz0, pz ? lz1 : hz1}, fz[2] = {pz ? hz0 : lz0, pz ? hz1 : lz1};
-    const float bestT = S.bestT;
-    unsigned hitmask = 0u;
-#pragma unroll
-    for(int w = 0; w < 2; w++)
-    {
-      // four children at a time (one byte each): where the bits of a hit child go in the 32-bit hit mask.
-      // internal child: meta = 0x20 | (24 + slot) -> bit 24 + (slot ^ octinv), one bit;
-      // leaf child: meta = unary count << 5 | triangle offset -> `count` bits from bit `offset`.
-      const unsigned meta4 = __float_as_uint(w == 0 ? q1.z : q1.w);
-      const unsigned inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;         // bit 4 of a byte set <=> internal (24..31)
-      const unsigned innerMask4 = (inner4 >> 4) * 0x07u;                      // 0x07 per internal byte
-      const unsigned bitIndex4 = (meta4 ^ (octinv * 0x01010101u & innerMask4)) & 0x1f1f1f1fu;
-      const unsigned bits4 = (meta4 >> 5) & 0x07070707u;
-#pragma unroll
-      for(int k = 0; k < 4; k++)
-      {
-        const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), fsx, fox);
-        const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), fsy, foy);
-        const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), fsz, foz);
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * 1.000002f));
-        const unsigned piece = ((bits4 >> (8 * k)) & 0xffu) << ((bitIndex4 >> (8 * k)) & 0xffu);
-        hitmask |= (tn <= tf) ? piece : 0u;
-      }
-    }
-    G = make_uint2(__float_as_uint(q1.x), (hitmask & 0xff000000u) | imask);
-    T = make_uint2(__float_as_uint(q1.y), hitmask & 0x00ffffffu);
+    w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, S.bestT, G, T, tc);
   }
   // triangles of this node that the ray's boxes touched
   while(T.y != 0u)
@@ -135,7 +148,11 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     const float4 a = tris[s * VKRT_TRI_QUADS + 0];
     const float4 b = tris[s * VKRT_TRI_QUADS + 1];
     const float4 c = tris[s * VKRT_TRI_QUADS + 2];
-    if(COUNT) nTris++;
+    if(COUNT)
+    {
+      tc.tris++;
+      if((int)lane_id() == __ffsll((long long)__ballot(1)) - 1) tc.waveTriSteps++;
+    }
     float t, u, v;
     if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
     {
@@ -172,20 +189,156 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
   return true;
 }
 
+// ---- variant with triangle postponing -----------------------------------------------------------------------------
+// Measured on the 1080p atrium (profiles/r01_experiments.md #17): with the immediate `while(T.y)` loop above a node
+// step runs at ~47 % lane efficiency but a triangle step at ~7 % (0.35 triangles per node visit, so nearly every wave
+// step has a few lanes with triangles and everyone else waits).  Here a lane keeps its pending triangle group T next
+// to its node group G; the wave tests triangles (one per lane per iteration) only when at least sc.triThreshold lanes
+// hold one, or when no lane has node work left.  A second group arriving while T is still pending is parked on the
+// top end of the lane's stack column (at most VKRT_W8_MAX_POSTPONED per lane, else tested at once).
+// The result does not depend on the order (closest = smallest t, ties -> smallest triangle id; any = exists).
+template <bool COUNT, bool ANYHIT>
+VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, uint2* stk, int stride, RayHit& hit, TravCount& tc)
+{
+  const float4* __restrict__ nodes = sc.nodes;
+  const float4* __restrict__ tris = sc.tris;
+  const int cap = (int)(sc.stackCap >> 1);
+  const unsigned thresh = sc.triThreshold;
+  const f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  const bool px = !(id.x < 0.0f), py = !(id.y < 0.0f), pz = !(id.z < 0.0f);
+  const unsigned octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+  float bestT = tmax, bestU = 0.0f, bestV = 0.0f;
+  int bestSlot = -1, bestGid = -1;
+  uint2 G = make_uint2(0u, sc.rootRef == VKRT_TRAV_DONE ? 0u : 0x80000000u);
+  uint2 T = make_uint2(0u, 0u);
+  int sp = 0, nPost = 0;
+  unsigned steps = sc.stepLimit;
+
+  // one triangle of T; returns true when an any-hit ray is finished
+  auto testOne = [&]() -> bool {
+    const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
+    T.y &= T.y - 1u;
+    const unsigned s = T.x + i;
+    const float4 a = tris[s * VKRT_TRI_QUADS + 0];
+    const float4 b = tris[s * VKRT_TRI_QUADS + 1];
+    const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+    if(COUNT)
+    {
+      tc.tris++;
+      if((int)lane_id() == __ffsll((long long)__ballot(1)) - 1) tc.waveTriSteps++;
+    }
+    float t, u, v;
+    if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v) && t > tmin)
+    {
+      if(ANYHIT)
+      {
+        if(t < tmax)
+        {
+          bestSlot = (int)s; bestT = t;
+          return true;
+        }
+      }
+      else
+      {
+        const int gid = __float_as_int(c.y);
+        if(t < bestT || (t == bestT && gid < bestGid))
+        {
+          bestT = t; bestU = u; bestV = v; bestSlot = (int)s; bestGid = gid;
+        }
+      }
+    }
+    return false;
+  };
+
+  bool done = G.y == 0u;
+  while(!done)
+  {
+    if(G.y & 0xff000000u)
+    {
+      // nearest pending internal child of the group; the rest of the group waits on the stack
+      const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
+      const unsigned slot = (bitIdx - 24u) ^ octinv;
+      const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
+      G.y &= ~(1u << bitIdx);
+      if((G.y & 0xff000000u) && sp + nPost < cap)
+      {
+        stk[sp * stride] = G;
+        sp++;
+      }
+      uint2 Tn;
+      w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bestT, G, Tn, tc);
+      if(Tn.y != 0u)
+      {
+        if(T.y != 0u)
+        {
+          if(nPost < VKRT_W8_MAX_POSTPONED && sp + nPost < cap)
+          {
+            nPost++;
+            stk[(cap - nPost) * stride] = T;  // parked groups grow down from the top of the lane's column
+          }
+          else
+          {
+            while(T.y != 0u)
+              if(testOne())
+              {
+                done = true;
+                break;
+              }
+            if(done)
+              break;
+          }
+        }
+        T = Tn;
+      }
+    }
+    // refill G from the node stack and T from the parked groups
+    if((G.y & 0xff000000u) == 0u && sp > 0)
+    {
+      sp--;
+      G = stk[sp * stride];
+    }
+    if(T.y == 0u && nPost > 0)
+    {
+      T = stk[(cap - nPost) * stride];
+      nPost--;
+    }
+    const bool hasT = T.y != 0u, hasG = (G.y & 0xff000000u) != 0u;
+    const unsigned nT = (unsigned)__popcll(__ballot(hasT));
+    if(nT >= thresh || __ballot(hasG) == 0ull)
+    {
+      if(hasT && testOne())
+        break;
+    }
+    if(!hasG && T.y == 0u && nPost == 0)
+      break;
+    if(--steps == 0u)
+      break;
+  }
+  hit.t = bestT; hit.u = bestU; hit.v = bestV; hit.slot = bestSlot;
+}
+
 template <bool COUNT>
 VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, uint2* stk, int stride, RayHit& hit,
-                             unsigned& nNodes, unsigned& nTris)
+                             TravCount& tc)
 {
+  if(sc.triThreshold != 0u)  // launch-uniform
+  {
+    if(anyHit)
+      traverse_wide8_postpone<COUNT, true>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
+    else
+      traverse_wide8_postpone<COUNT, false>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
+    return;
+  }
   W8State S;
   w8_begin(sc, S, o, d, tmax, anyHit);
   if(S.G.y != 0u)
   {
     if(anyHit)  // workgroup-uniform in the wavefront kernels: two specialised loops, no per-triangle branch
-      while(w8_iterate<COUNT, true>(sc, S, tmin, stk, stride, nNodes, nTris))
+      while(w8_iterate<COUNT, true>(sc, S, tmin, stk, stride, tc))
       {
       }
     else
-      while(w8_iterate<COUNT, false>(sc, S, tmin, stk, stride, nNodes, nTris))
+      while(w8_iterate<COUNT, false>(sc, S, tmin, stk, stride, tc))
       {
       }
   }
@@ -195,10 +348,10 @@ VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float t
 // layout dispatch used by the kernels: stkWords = this lane's LDS stack column (4-byte words, stride in words)
 template <bool COUNT, bool WIDE>
 VKRT_DEV void traverse_any(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int tid, int block, RayHit& hit,
-                           unsigned& nNodes, unsigned& nTris)
+                           TravCount& tc)
 {
   if(WIDE)
-    traverse_wide8<COUNT>(sc, o, d, tmin, tmax, anyHit, ((uint2*)lds) + tid, block, hit, nNodes, nTris);
+    traverse_wide8<COUNT>(sc, o, d, tmin, tmax, anyHit, ((uint2*)lds) + tid, block, hit, tc);
   else
-    traverse<COUNT>(sc, o, d, tmin, tmax, anyHit, lds + tid, block, hit, nNodes, nTris);
+    traverse<COUNT>(sc, o, d, tmin, tmax, anyHit, lds + tid, block, hit, tc);
 }

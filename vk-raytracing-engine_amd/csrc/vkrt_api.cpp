@@ -19,6 +19,8 @@
 #include "bvh_host.h"
 #include "device_scene.h"
 #include "kernels.h"
+
+#define VKRT_TRI_THRESHOLD_DEFAULT 1
 #include "lbvh.h"
 
 namespace {
@@ -484,6 +486,16 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     }
   }
   s->dev.stepLimit = 4u * (s->info.node_count + s->info.triangle_count) + 64u;
+  s->dev.triThreshold = 0;
+  if(s->dev.layout == 1)
+  {
+    // triangle postponing (traverse_wide.h): lanes with pending triangles before a wave tests them; 0 = immediate
+    const char* e = getenv("VKRT_TRI_THRESHOLD");
+    const int v = e ? atoi(e) : VKRT_TRI_THRESHOLD_DEFAULT;
+    s->dev.triThreshold = (uint32_t)(v < 0 ? 0 : (v > 65 ? 65 : v));
+    if(s->dev.triThreshold != 0u)
+      s->dev.stackCap += 2 * VKRT_W8_MAX_POSTPONED;  // room for parked triangle groups (uint2 entries)
+  }
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
   if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)
     return fail(VKRT_ERR_UNSUPPORTED, "BVH depth %u needs a %zu-byte LDS stack per workgroup (limit 64 KiB)", s->info.max_depth,
@@ -731,11 +743,12 @@ int vkrt_counters_read(vkrt_scene* s, vkrt_counters* out)
   HIP_TRY(hipDeviceSynchronize());
   DevCounters h;
   HIP_TRY(hipMemcpy(&h, s->counters, sizeof h, hipMemcpyDeviceToHost));
-  unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for(int sl = 0; sl < VKRT_COUNTER_SLOTS; sl++)
-    for(int k = 0; k < 8; k++) t[k] += h.v[sl][k];
+    for(int k = 0; k < 10; k++) t[k] += h.v[sl][k];
   out->rays_closest = t[0]; out->rays_shadow = t[1]; out->hits = t[2]; out->diffuse_hits = t[3];
   out->tex_taps = t[4]; out->pixels = t[5]; out->nodes_visited = t[6]; out->tris_tested = t[7];
+  out->wave_node_steps = t[8]; out->wave_tri_steps = t[9];
   return VKRT_OK;
 }
 

@@ -170,14 +170,14 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_init(const TraceParams P, const
   }
   __shared__ unsigned wsum[2 * (WF_BLOCK / 64 + 1)];
   appendQueues(qPtr(B, 0, 0), &B.ctrl[0], qPtr(B, 0, 1), &B.ctrl[1], alive, false, w, lane, wsum);
-  __shared__ unsigned long long red[8 * (WF_BLOCK / 64)];
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
   const unsigned vals[6] = {0, 0, 0, 0, 0, nPixels};
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 6, red);
 }
 
 // ---- traversal: one thread per queued ray, workgroups homogeneous in ray type -----------------------------------
-template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
+template <bool COUNT, bool WIDE, int TB>
+__global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
 {
   extern __shared__ int lds_stack[];
   const int par = round & 1;
@@ -187,27 +187,28 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse(const TraceParams P, c
     B.ctrl[(par ^ 1) * 2 + 0] = 0u;  // next round's counts; this round's k_wf_shade appends to them
     B.ctrl[(par ^ 1) * 2 + 1] = 0u;
   }
-  const unsigned nbC = (countC + WF_BLOCK - 1) / WF_BLOCK, nbS = (countS + WF_BLOCK - 1) / WF_BLOCK;
+  const unsigned nbC = (countC + TB - 1) / TB, nbS = (countS + TB - 1) / TB;
   if(blockIdx.x >= nbC + nbS)
     return;
   const bool anyHit = blockIdx.x >= nbC;  // workgroup-uniform
-  const unsigned qi = (anyHit ? blockIdx.x - nbC : blockIdx.x) * WF_BLOCK + threadIdx.x;
+  const unsigned qi = (anyHit ? blockIdx.x - nbC : blockIdx.x) * TB + threadIdx.x;
   const unsigned count = anyHit ? countS : countC;
-  unsigned nNodes = 0, nTris = 0, nRays = 0;
+  unsigned nRays = 0;
+  TravCount tc;
   if(qi < count)
   {
     const unsigned pid = qPtr(B, par, anyHit ? 1 : 0)[qi];
     float4* r = rec(B, pid);
     const float4 r0 = r[0], r1 = r[1];
     RayHit hit;
-    traverse_any<COUNT, WIDE>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, WF_BLOCK, hit,
-                              nNodes, nTris);
+    traverse_any<COUNT, WIDE>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit,
+                              tc);
     r[2] = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
     nRays = 1;
   }
-  __shared__ unsigned long long red[8 * (WF_BLOCK / 64)];
-  const unsigned vals[8] = {anyHit ? 0u : nRays, anyHit ? nRays : 0u, 0, 0, 0, 0, nNodes, nTris};
-  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 8 : 2, red);
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (TB / 64)];
+  const unsigned vals[10] = {anyHit ? 0u : nRays, anyHit ? nRays : 0u, 0, 0, 0, 0, tc.nodes, tc.tris, tc.waveNodeSteps, tc.waveTriSteps};
+  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 10 : 2, red);
 }
 
 // ---- traversal variant: persistent workgroups, idle lanes refilled from the queue inside the loop ------------------
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse_refill(const TracePara
   W8State S;
   S.G = make_uint2(0u, 0u); S.sp = 0; S.steps = 0; S.anyHit = anyHit;
   S.o = mk3(0.0f); S.d = mk3(0.0f); S.id = mk3(0.0f); S.tmax = 0.0f; S.bestT = 0.0f; S.bestU = 0.0f; S.bestV = 0.0f; S.bestSlot = -1; S.bestGid = -1;
-  unsigned nRays = 0, nNodes = 0, nTris = 0;
+  unsigned nRays = 0;
+  TravCount tc;
   for(;;)
   {
     const unsigned long long idleMask = __ballot(!active);
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse_refill(const TracePara
     }
     if(active)
     {
-      const bool more = anyHit ? w8_iterate<COUNT, true>(P.sc, S, 0.001f, stk, WF_BLOCK, nNodes, nTris)
-                               : w8_iterate<COUNT, false>(P.sc, S, 0.001f, stk, WF_BLOCK, nNodes, nTris);
+      const bool more = anyHit ? w8_iterate<COUNT, true>(P.sc, S, 0.001f, stk, WF_BLOCK, tc)
+                               : w8_iterate<COUNT, false>(P.sc, S, 0.001f, stk, WF_BLOCK, tc);
       if(!more)
       {
         rec(B, pid)[2] = make_float4(S.bestT, S.bestU, S.bestV, __int_as_float(S.bestSlot));
@@ -317,9 +319,9 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_traverse_refill(const TracePara
       }
     }
   }
-  __shared__ unsigned long long red[8 * (WF_BLOCK / 64)];
-  const unsigned vals[8] = {anyHit ? 0u : nRays, anyHit ? nRays : 0u, 0, 0, 0, 0, nNodes, nTris};
-  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 8 : 2, red);
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
+  const unsigned vals[10] = {anyHit ? 0u : nRays, anyHit ? nRays : 0u, 0, 0, 0, 0, tc.nodes, tc.tris, tc.waveNodeSteps, tc.waveTriSteps};
+  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 10 : 2, red);
 }
 
 // ---- shade, closest-hit results: rchit / rmiss, then shadow request or accumulation (heavy; few waves/SIMD) ---------
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_closest(const TraceParams
   }
   appendQueues(qPtr(B, par ^ 1, 0), &B.ctrl[(par ^ 1) * 2 + 0], qPtr(B, par ^ 1, 1), &B.ctrl[(par ^ 1) * 2 + 1], toClosest, toShadow, pid, lane,
                wsum);
-  __shared__ unsigned long long red[8 * (WF_BLOCK / 64)];
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
   const unsigned vals[5] = {0, 0, st.hits, st.diffuse, st.taps};
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 5, red);
 }
@@ -425,12 +427,14 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int c
   if(timing)
     timing->used = 0;
   static int refill = -1, refillMin = 16, refillBlocks = 0;
+  static unsigned travBlock = 64;
   if(refill < 0)
   {
     const char* e = getenv("VKRT_WF_TRAVERSE");
     refill = (e && !strcmp(e, "refill")) ? 1 : 0;
     if((e = getenv("VKRT_WF_REFILL"))) refillMin = std::max(1, std::min(64, atoi(e)));
     if((e = getenv("VKRT_WF_BLOCKS_PER_CU"))) refillBlocks = atoi(e);
+    if((e = getenv("VKRT_WF_TRAV_BLOCK"))) travBlock = atoi(e) == 64 ? 64u : atoi(e) == 128 ? 128u : 256u;
   }
   int perCU = 4;
   if(refill && wide)
@@ -451,15 +455,28 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int c
       if(count) hipLaunchKernelGGL(k_wf_traverse_refill<true>, pg, bb, lds, stream, P, B, r, (unsigned)refillMin);
       else hipLaunchKernelGGL(k_wf_traverse_refill<false>, pg, bb, lds, stream, P, B, r, (unsigned)refillMin);
     }
-    else if(wide)
-    {
-      if(count) hipLaunchKernelGGL((k_wf_traverse<true, true>), grid, bb, lds, stream, P, B, r);
-      else hipLaunchKernelGGL((k_wf_traverse<false, true>), grid, bb, lds, stream, P, B, r);
-    }
     else
     {
-      if(count) hipLaunchKernelGGL((k_wf_traverse<true, false>), grid, bb, lds, stream, P, B, r);
-      else hipLaunchKernelGGL((k_wf_traverse<false, false>), grid, bb, lds, stream, P, B, r);
+      // one wavefront per workgroup by default: a finished wave frees its slot and LDS without waiting for three others
+      const dim3 tg((work + travBlock - 1) / travBlock + 2), tb(travBlock);
+      const size_t tlds = (size_t)P.sc.stackCap * travBlock * sizeof(int);
+#define VKRT_TRAV_LAUNCH(C, W, TB) hipLaunchKernelGGL((k_wf_traverse<C, W, TB>), tg, tb, tlds, stream, P, B, r)
+      if(travBlock == 64)
+      {
+        if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 64); else VKRT_TRAV_LAUNCH(false, true, 64); }
+        else { if(count) VKRT_TRAV_LAUNCH(true, false, 64); else VKRT_TRAV_LAUNCH(false, false, 64); }
+      }
+      else if(travBlock == 128)
+      {
+        if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 128); else VKRT_TRAV_LAUNCH(false, true, 128); }
+        else { if(count) VKRT_TRAV_LAUNCH(true, false, 128); else VKRT_TRAV_LAUNCH(false, false, 128); }
+      }
+      else
+      {
+        if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 256); else VKRT_TRAV_LAUNCH(false, true, 256); }
+        else { if(count) VKRT_TRAV_LAUNCH(true, false, 256); else VKRT_TRAV_LAUNCH(false, false, 256); }
+      }
+#undef VKRT_TRAV_LAUNCH
     }
     if(timed)
     {

@@ -69,15 +69,19 @@ void HelloVkrt::createTopLevelAsGltf()
 
 void HelloVkrt::createOffscreenRender()
 {
-  if(m_offscreenColor)
+  float** planes[6] = {&m_offscreenColor, &m_positionTexture, &m_normalTexture, &m_roughnessTexture, &m_accumulatedTexture, &m_displayImage};
+  const size_t px = (size_t)m_size.width * m_size.height;
+  const size_t bytes[6] = {px * 16, px * 16, px * 16, px * 8, px * 16, px * 16};
+  if(hipSetDevice(m_device) != hipSuccess)
+    throw std::runtime_error("createOffscreenRender: hipSetDevice failed");
+  for(int k = 0; k < 6; k++)
   {
-    (void)hipFree(m_offscreenColor);
-    m_offscreenColor = nullptr;
+    if(*planes[k]) (void)hipFree(*planes[k]);
+    *planes[k] = nullptr;
+    if(hipMalloc((void**)planes[k], bytes[k]) != hipSuccess)
+      throw std::runtime_error("createOffscreenRender: hipMalloc failed");
+    (void)hipMemset(*planes[k], 0, bytes[k]);
   }
-  const size_t bytes = (size_t)m_size.width * m_size.height * 4 * sizeof(float);
-  if(hipSetDevice(m_device) != hipSuccess || hipMalloc((void**)&m_offscreenColor, bytes) != hipSuccess)
-    throw std::runtime_error("createOffscreenRender: hipMalloc failed");
-  (void)hipMemset(m_offscreenColor, 0, bytes);
 }
 
 void HelloVkrt::updateUniformBuffer() { m_hostUBO = makeGlobalUniforms(CameraManip, m_size.width, m_size.height); }
@@ -110,6 +114,38 @@ void HelloVkrt::pathtrace(const float clearColor[4])
   check(vkrt_pathtrace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, m_offscreenColor, nullptr), "vkrt_pathtrace");
 }
 
+void HelloVkrt::rasterizeGltf(const float clearColor[4])
+{
+  if(!m_scene || !m_offscreenColor)
+    throw std::runtime_error("rasterizeGltf before scene/offscreen image creation");
+  const vkrt_shard shard{(uint32_t)m_size.width, (uint32_t)m_size.height, 0, 1, 0};
+  const vkrt_gbuffer g{m_offscreenColor, m_positionTexture, m_normalTexture, m_roughnessTexture};
+  check(vkrt_gbuffer_raycast(m_scene, clearColor, m_pcRay.lightsCount /* m_pcRaster.lightsCount, :323 */, &m_hostUBO, &shard, &g, nullptr),
+        "vkrt_gbuffer_raycast");
+}
+
+void HelloVkrt::raytraceRasterizedScene()
+{
+  if(m_stopAtMaxFrames && m_pcRay.frame >= m_maxFrames)
+    return;
+  const vkrt_trace_opts opts{m_seed, m_traceFlags};
+  const vkrt_shard shard{(uint32_t)m_size.width, (uint32_t)m_size.height, 0, 1, 0};
+  const vkrt_gbuffer g{m_offscreenColor, m_positionTexture, m_normalTexture, m_roughnessTexture};
+  check(vkrt_hybrid_trace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, &g, m_accumulatedTexture, nullptr), "vkrt_hybrid_trace");
+}
+
+void HelloVkrt::drawPost(std::vector<float>& displayRgba)
+{
+  m_pcPost.aspectRatio = (float)m_size.width / (float)m_size.height;
+  m_pcPost.useGI = m_pcRay.useGI;
+  const uint32_t n = (uint32_t)((size_t)m_size.width * m_size.height);
+  check(vkrt_post(m_device, &m_pcPost, n, m_offscreenColor, m_accumulatedTexture, m_displayImage, nullptr), "vkrt_post");
+  displayRgba.resize((size_t)n * 4);
+  if(hipDeviceSynchronize() != hipSuccess ||
+     hipMemcpy(displayRgba.data(), m_displayImage, displayRgba.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+    throw std::runtime_error("drawPost: hipMemcpy failed");
+}
+
 void HelloVkrt::onResize(int w, int h)
 {
   setup(w, h);
@@ -121,8 +157,12 @@ void HelloVkrt::destroyResources()
 {
   if(m_scene) vkrt_scene_destroy(m_scene);
   m_scene = nullptr;
-  if(m_offscreenColor) (void)hipFree(m_offscreenColor);
-  m_offscreenColor = nullptr;
+  float** planes[6] = {&m_offscreenColor, &m_positionTexture, &m_normalTexture, &m_roughnessTexture, &m_accumulatedTexture, &m_displayImage};
+  for(int k = 0; k < 6; k++)
+  {
+    if(*planes[k]) (void)hipFree(*planes[k]);
+    *planes[k] = nullptr;
+  }
 }
 
 void HelloVkrt::downloadImage(std::vector<float>& rgba) const
@@ -177,6 +217,10 @@ AppConfig parseConfig(const std::string& text)
   c.seed = j["seed"].integer(c.seed);
   c.seedPerFrame = j["seedPerFrame"].boolean(c.seedPerFrame);
   c.build = j["build"].string(c.build);
+  c.mode = j["mode"].string(c.mode);  // "pathtrace" (rtMode 1) or "hybrid" (rtMode 0, the reference's start-up mode)
+  c.useShadows = j["useShadows"].boolean(c.useShadows);
+  c.useAO = j["useAO"].boolean(c.useAO);
+  c.useGI = j["useGI"].boolean(c.useGI);
   c.output = j["output"].string("");
   if(j.has("clearColor"))
     for(int k = 0; k < 4; k++) c.clearColor[k] = (float)j["clearColor"][(size_t)k].number(1.0);

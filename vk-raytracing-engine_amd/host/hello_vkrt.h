@@ -46,6 +46,10 @@ public:
   void resetFrame();                                      // :1501-1504
   void updateFrame();                                     // :1506-1521
   void pathtrace(const float clearColor[4]);              // :1423-1448
+  // hybrid mode (rtMode == 0): main.cpp:510-561 = rasterizeGltf -> raytraceRasterizedScene -> drawPost
+  void rasterizeGltf(const float clearColor[4]);          // :583-615 (ray-cast G-buffer: no raster path from HIP)
+  void raytraceRasterizedScene();                         // :1450-1473
+  void drawPost(std::vector<float>& displayRgba);         // :882-897 + post.frag (composite + gamma), downloaded
   void onResize(int w, int h);                            // :620-626
   void destroyResources();                                // :518-578
 
@@ -66,12 +70,19 @@ public:
   uint32_t m_seed = 0;            // replaces int(clockARB()) (raytrace.rgen:27); advanced every frame
   uint32_t m_buildFlags = VKRT_BUILD_DEFAULT;
   uint32_t m_traceFlags = 0;
+  PushConstantPost m_pcPost{1.0f, 0, 0, 0};  // rtMode 0 = hybrid (hello_vulkan.cpp:917), 1 = path tracer
 
 private:
   void check(int rc, const char* what) const;
   int m_device;
   vkrt_scene* m_scene = nullptr;
   float* m_offscreenColor = nullptr;  // device rgba32f
+  // hybrid planes (createOffscreenRender :637-826): position, normal, rough/metal, accumulation, display
+  float* m_positionTexture = nullptr;
+  float* m_normalTexture = nullptr;
+  float* m_roughnessTexture = nullptr;
+  float* m_accumulatedTexture = nullptr;
+  float* m_displayImage = nullptr;
   bool m_blasRequested = false;
   // updateFrame()'s function-local statics in the reference (:1508-1509)
   vkrt_mat4 m_refCamMatrix{};
@@ -95,6 +106,8 @@ struct AppConfig
   Vec3 eye{0, 0, 15}, center{0, 0, 0}, up{0, 1, 0};
   float fov = 60.0f;
   std::string build = "sah";
+  std::string mode = "pathtrace";
+  bool useShadows = true, useAO = true, useGI = false;  // hello_vulkan.cpp:913-915
   std::string output;
   std::string scenePath() const { return scenes.at((size_t)scene); }
 };

@@ -4,6 +4,7 @@
 // writes the rgba32f image (PFM) and a gamma-2.2 preview (PPM, post.frag:39).
 #include <chrono>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -57,13 +58,22 @@ int main(int argc, char** argv)
     printf("scene %s: %u triangles, %u BVH nodes (depth %u, SAH %.1f), %zu lights; load+build %.1f ms\n", scenePath.c_str(),
            ai.triangle_count, ai.node_count, ai.max_depth, ai.sah_cost, helloVk.m_gltfScene.m_lights.size(), loadMs);
 
+    const bool hybrid = cfg.mode == "hybrid";
+    helloVk.m_pcPost.rtMode = hybrid ? 0 : 1;
+    helloVk.m_pcRay.useShadows = cfg.useShadows; helloVk.m_pcRay.useAO = cfg.useAO; helloVk.m_pcRay.useGI = cfg.useGI;
     double traceMs = 0;
-    for(int f = 0; f < cfg.frames; f++)                         // main.cpp:441 loop body, rtMode == 1
+    for(int f = 0; f < cfg.frames; f++)                         // main.cpp:441 loop body
     {
       helloVk.updateUniformBuffer();                            // main.cpp:503
       helloVk.updateFrame();                                    // main.cpp:504
       helloVk.m_seed = (uint32_t)cfg.seed + (cfg.seedPerFrame ? (uint32_t)f : 0u);
-      helloVk.pathtrace(cfg.clearColor);                        // main.cpp:507
+      if(!hybrid)
+        helloVk.pathtrace(cfg.clearColor);                      // main.cpp:507
+      else
+      {
+        helloVk.rasterizeGltf(cfg.clearColor);                  // main.cpp:513
+        helloVk.raytraceRasterizedScene();                      // main.cpp:547
+      }
       traceMs += helloVk.lastTraceMs();
     }
     const vkrt_counters c = helloVk.counters();
@@ -75,7 +85,15 @@ int main(int argc, char** argv)
     if(!out.empty())
     {
       std::vector<float> img;
-      helloVk.downloadImage(img);
+      if(hybrid)
+      {  // composite of the raster plane and the ray-traced plane (post.frag:41-47), before gamma for the PFM
+        std::vector<float> display;
+        helloVk.drawPost(display);
+        img.resize(display.size());
+        for(size_t k = 0; k < display.size(); k++) img[k] = std::pow(display[k], 2.2f);
+      }
+      else
+        helloVk.downloadImage(img);
       writePFM(out + ".pfm", img, cfg.width, cfg.height);
       writePPM(out + ".ppm", img, cfg.width, cfg.height);
       printf("wrote %s.pfm / %s.ppm\n", out.c_str(), out.c_str());
