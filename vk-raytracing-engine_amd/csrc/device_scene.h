@@ -24,14 +24,28 @@ static_assert(sizeof(DevInstance) == 96, "DevInstance");
 // the per-CU L1/TA processes one 16-byte lane-load per tag lookup, so records are laid out for few,
 // wide, aligned loads instead of the ~70 dword loads per hit that the raw SoA layout needs.
 //   vertex  : 2 x float4 = (pos.xyz, nrm.x) (nrm.y, nrm.z, uv.x, uv.y); tangents stay float4
-//   material: 64 bytes  = GltfPBRMaterial (52 B) padded to four aligned float4
+//   material: 128 bytes = GltfPBRMaterial (52 B) padded to four aligned float4 + the descriptors of its four
+//             textures (base colour, metallic-roughness, normal, emissive), so a hit reaches its texels in
+//             one hop from the material record instead of two (no separate descriptor-table lookup)
 //   primInfo: 16 bytes  = PrimMeshInfo (12 B) + pad
+struct DevTexRef
+{
+  uint32_t offset;  // first texel in the RGBA8 pool (0 when invalid)
+  uint32_t wh;      // width | height << 16 (1 | 1 << 16 when invalid)
+  uint32_t flags;   // bit 0: index refers to an uploaded texture; bit 1: sRGB
+  uint32_t pad;
+};
+#define VKRT_TEXREF_BASE 0
+#define VKRT_TEXREF_MR 1
+#define VKRT_TEXREF_NORMAL 2
+#define VKRT_TEXREF_EMISSIVE 3
 struct DevMaterial
 {
   GltfPBRMaterial m;
   int32_t pad[3];
+  DevTexRef tex[4];
 };
-static_assert(sizeof(DevMaterial) == 64, "DevMaterial");
+static_assert(sizeof(DevMaterial) == 128, "DevMaterial");
 struct DevPrimInfo
 {
   PrimMeshInfo p;
@@ -72,7 +86,7 @@ struct DevScene
   const DevInstance* instances;
   const DevTexture* textures;
   const uint32_t* texels;     // RGBA8 pool
-  const float* srgbLut;       // 256 floats
+  const float* srgbLut;       // 512 floats: [0,256) sRGB decode of i/255, [256,512) i/255 (UNORM decode)
   const float4* nodes;
   const float4* tris;
   const uint4* triShade;      // per triangle slot: absolute vertex indices i0,i1,i2 and max(0, materialIndex)

@@ -87,8 +87,10 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
   uint32_t x, y, lrow;
   unsigned nClosest = 0;
   TravCount tc;
+  __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
+  st.lut = ldsTexelLut(P.sc, lut);
   if(pixelOf(P, x, y, lrow))
   {
     const size_t p = (size_t)lrow * P.fullW + x;
@@ -207,8 +209,10 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
   uint32_t x, y, lrow;
   unsigned nClosest = 0, nShadow = 0, nPixels = 0;
   TravCount tc;
+  __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
+  st.lut = ldsTexelLut(P.sc, lut);
   if(pixelOf(P, x, y, lrow))
   {
     nPixels = 1;

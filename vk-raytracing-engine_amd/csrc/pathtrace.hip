@@ -34,8 +34,10 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
   bool exhausted = false;  // wave-uniform: work counter ran out
   unsigned nClosest = 0, nShadow = 0, nPixels = 0;
   TravCount tc;
+  __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
+  st.lut = ldsTexelLut(P.sc, lut);
   const uint32_t totalWork = P.tileCount * 64u;
 
   for(;;)
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
       bool shadowHit = false;
       bool accumulate = true;
       if(!shadow)
-        accumulate = !afterClosestRay(P, L, hit, d, st);
+        accumulate = !afterClosestRay(P, L, hit, hit.slot >= 0 ? P.sc.triShade[hit.slot] : make_uint4(0u, 0u, 0u, 0u), d, st);
       else
         shadowHit = hit.slot >= 0;
       if(accumulate)

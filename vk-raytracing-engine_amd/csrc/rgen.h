@@ -85,10 +85,11 @@ VKRT_DEV uint32_t globalRow(const TraceParams& P, uint32_t lrow)
 
 // After the closest-hit ray of the current segment: run rchit / rmiss (raytrace.rgen:64-75).
 // Returns true when a shadow ray has to be traced before the segment can be accumulated (rgen:79).
-VKRT_DEV bool afterClosestRay(const TraceParams& P, LaneState& L, const RayHit& hit, f3 rayDir, ShadeStats& st)
+// `ts`: the hit triangle's shading record (sc.triShade[hit.slot]); ignored on a miss.
+VKRT_DEV bool afterClosestRay(const TraceParams& P, LaneState& L, const RayHit& hit, const uint4 ts, f3 rayDir, ShadeStats& st)
 {
   if(hit.slot >= 0)
-    closestHitShader(P.sc, P.pc, hit, rayDir, L.prd, st);
+    closestHitShader(P.sc, P.pc, hit, ts, rayDir, L.prd, st);
   else
     missShader(P.pc, L.prd);
   if(!L.prd.isSpecular && L.prd.depth != 100u)

@@ -24,51 +24,94 @@ struct Payload
 struct ShadeStats
 {
   unsigned hits, diffuse, taps;
+  const float* lut;  // 512-entry texel decode table (DevScene::srgbLut or the workgroup's LDS copy, see ldsTexelLut)
 };
+
+// Copy the 2-KB texel decode table into LDS (call from every thread of the block, before any divergence).
+VKRT_DEV const float* ldsTexelLut(const DevScene& sc, float* lds512)
+{
+  for(unsigned i = threadIdx.x; i < 512u; i += blockDim.x)
+    lds512[i] = sc.srgbLut[i];
+  __syncthreads();
+  return lds512;
+}
 
 struct f4 { float x, y, z, w; };
 
+// i mod n in [0, n) for n > 0 (REPEAT addressing); power-of-two sizes take the mask path
 VKRT_DEV int wrapi(int i, int n)
 {
+  if((n & (n - 1)) == 0)
+    return i & (n - 1);
   int m = i % n;
   return m < 0 ? m + n : m;
 }
-VKRT_DEV f4 fetchTexel(const DevScene& sc, const DevTexture& tx, int x, int y)
+
+// texture(): bilinear, REPEAT, LOD 0, RGBA8 UNORM / sRGB (hello_vulkan.cpp:448-454), split in three steps so a hit can
+// issue the texel loads of all its textures back to back: footprint (addresses + weights), 4 loads, decode + blend.
+struct TexTap
 {
-  const uint32_t p = sc.texels[tx.offset + (uint32_t)y * tx.width + (uint32_t)x];
-  const uint32_t r = p & 255u, g = (p >> 8) & 255u, b = (p >> 16) & 255u, a = p >> 24;
+  uint32_t i00, i10, i01, i11;  // texel indices into the pool
+  float ax, ay;
+  uint32_t lutBase;             // 0: sRGB decode, 256: UNORM decode (rgb; alpha is always UNORM)
+  bool white;                   // index out of range: 1x1 white dummy (hello_vulkan.cpp:468-472)
+};
+VKRT_DEV void texFootprint(uint32_t offset, uint32_t width, uint32_t height, bool srgb, bool valid, bool want, float u, float v, TexTap& t)
+{
+  float fx = u * (float)width - 0.5f;
+  float fy = v * (float)height - 0.5f;
+  if(!(fabsf(fx) < 1.0e9f)) fx = 0.0f;
+  if(!(fabsf(fy) < 1.0e9f)) fy = 0.0f;
+  const float flx = floorf(fx), fly = floorf(fy);
+  t.ax = fx - flx; t.ay = fy - fly;
+  const int w = (int)width, h = (int)height;
+  const int x0 = wrapi((int)flx, w), y0 = wrapi((int)fly, h);
+  const int x1 = x0 + 1 == w ? 0 : x0 + 1, y1 = y0 + 1 == h ? 0 : y0 + 1;
+  const bool live = want && valid;
+  const uint32_t r0 = offset + (uint32_t)y0 * width, r1 = offset + (uint32_t)y1 * width;
+  t.i00 = live ? r0 + (uint32_t)x0 : 0u; t.i10 = live ? r0 + (uint32_t)x1 : 0u;
+  t.i01 = live ? r1 + (uint32_t)x0 : 0u; t.i11 = live ? r1 + (uint32_t)x1 : 0u;
+  t.lutBase = srgb ? 0u : 256u;
+  t.white = !valid;
+}
+VKRT_DEV f4 texelDecode(const float* lut, uint32_t p, uint32_t base)
+{
   f4 o;
-  if(tx.srgb) { o.x = sc.srgbLut[r]; o.y = sc.srgbLut[g]; o.z = sc.srgbLut[b]; }
-  else { o.x = (float)r / 255.0f; o.y = (float)g / 255.0f; o.z = (float)b / 255.0f; }
-  o.w = (float)a / 255.0f;
+  o.x = lut[base + (p & 255u)]; o.y = lut[base + ((p >> 8) & 255u)]; o.z = lut[base + ((p >> 16) & 255u)];
+  o.w = lut[256u + (p >> 24)];
   return o;
 }
+VKRT_DEV f4 texBlend(const float* lut, const TexTap& tp, uint32_t p00, uint32_t p10, uint32_t p01, uint32_t p11)
+{
+  f4 r;
+  if(tp.white)
+  {
+    r.x = r.y = r.z = r.w = 1.0f;
+    return r;
+  }
+  const f4 t00 = texelDecode(lut, p00, tp.lutBase), t10 = texelDecode(lut, p10, tp.lutBase);
+  const f4 t01 = texelDecode(lut, p01, tp.lutBase), t11 = texelDecode(lut, p11, tp.lutBase);
+  const float ax = tp.ax, ay = tp.ay, bx = 1.0f - ax, by = 1.0f - ay;
+  r.x = (t00.x * bx + t10.x * ax) * by + (t01.x * bx + t11.x * ax) * ay;
+  r.y = (t00.y * bx + t10.y * ax) * by + (t01.y * bx + t11.y * ax) * ay;
+  r.z = (t00.z * bx + t10.z * ax) * by + (t01.z * bx + t11.z * ax) * ay;
+  r.w = (t00.w * bx + t10.w * ax) * by + (t01.w * bx + t11.w * ax) * ay;
+  return r;
+}
+// one texture by index through the descriptor table (G-buffer path; the path tracer's hit shader uses DevTexRef)
 VKRT_DEV f4 sampleTex(const DevScene& sc, int texIndex, float u, float v, ShadeStats& st)
 {
   st.taps++;
   f4 r;
   if(sc.textureCount == 0u || texIndex < 0 || texIndex >= (int)sc.textureCount)
   {
-    r.x = r.y = r.z = r.w = 1.0f;  // 1x1 white dummy (hello_vulkan.cpp:468-472)
+    r.x = r.y = r.z = r.w = 1.0f;
     return r;
   }
   const DevTexture tx = sc.textures[texIndex];
-  float fx = u * (float)tx.width - 0.5f;
-  float fy = v * (float)tx.height - 0.5f;
-  if(!(fabsf(fx) < 1.0e9f)) fx = 0.0f;
-  if(!(fabsf(fy) < 1.0e9f)) fy = 0.0f;
-  const float flx = floorf(fx), fly = floorf(fy);
-  const float ax = fx - flx, ay = fy - fly;
-  const int x0 = wrapi((int)flx, (int)tx.width), x1 = wrapi((int)flx + 1, (int)tx.width);
-  const int y0 = wrapi((int)fly, (int)tx.height), y1 = wrapi((int)fly + 1, (int)tx.height);
-  const f4 t00 = fetchTexel(sc, tx, x0, y0), t10 = fetchTexel(sc, tx, x1, y0);
-  const f4 t01 = fetchTexel(sc, tx, x0, y1), t11 = fetchTexel(sc, tx, x1, y1);
-  const float bx = 1.0f - ax, by = 1.0f - ay;
-  r.x = (t00.x * bx + t10.x * ax) * by + (t01.x * bx + t11.x * ax) * ay;
-  r.y = (t00.y * bx + t10.y * ax) * by + (t01.y * bx + t11.y * ax) * ay;
-  r.z = (t00.z * bx + t10.z * ax) * by + (t01.z * bx + t11.z * ax) * ay;
-  r.w = (t00.w * bx + t10.w * ax) * by + (t01.w * bx + t11.w * ax) * ay;
-  return r;
+  TexTap tp;
+  texFootprint(tx.offset, tx.width, tx.height, tx.srgb != 0u, true, true, u, v, tp);
+  return texBlend(st.lut, tp, sc.texels[tp.i00], sc.texels[tp.i10], sc.texels[tp.i01], sc.texels[tp.i11]);
 }
 
 // gltf.glsl:26-32
@@ -199,68 +242,102 @@ VKRT_DEV f3 xformNormal(const DevInstance& in, f3 n)
 }
 
 // raytrace.rchit:31-219
-VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, f3 worldRayDir, Payload& prd,
+// `ts` = sc.triShade[hit.slot] (vertex indices + material), fetched by the caller (the wavefront traversal kernel
+// leaves it in the path record next to the hit).
+VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, const uint4 ts, f3 worldRayDir, Payload& prd,
                                ShadeStats& st)
 {
   st.hits++;
   const float4 rec = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
-  const uint32_t instId = (uint32_t)__float_as_int(rec.z), primId = (uint32_t)__float_as_int(rec.w);
-  const DevInstance in = sc.instances[instId];
+  const uint32_t instId = (uint32_t)__float_as_int(rec.z);
   // rchit:34-50 (PrimMeshInfo lookup, three index fetches, vertexOffset, max(0, materialIndex)) is resolved once
   // per triangle at build time into a 16-byte record, so the attribute fetch below is one hop from the hit.
-  const uint4 ts = sc.triShade[hit.slot];
   const uint32_t i0 = ts.x, i1 = ts.y, i2 = ts.z, matIndex = ts.w;
-  (void)primId;
   const f3 b = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);  // rchit:68
 
   const float4 a0 = sc.vertexPN[2 * i0], b0 = sc.vertexPN[2 * i0 + 1];
   const float4 a1 = sc.vertexPN[2 * i1], b1 = sc.vertexPN[2 * i1 + 1];
   const float4 a2 = sc.vertexPN[2 * i2], b2 = sc.vertexPN[2 * i2 + 1];
-  const f3 pos = mk3(a0.x, a0.y, a0.z) * b.x + mk3(a1.x, a1.y, a1.z) * b.y + mk3(a2.x, a2.y, a2.z) * b.z;
-  const f3 worldPos = xformPoint(in, pos);
-  const f3 nrm = normalize3(mk3(a0.w, b0.x, b0.y) * b.x + mk3(a1.w, b1.x, b1.y) * b.y + mk3(a2.w, b2.x, b2.y) * b.z);
-  const f3 worldNrm = normalize3(xformNormal(in, nrm));
   const float4 tq0 = ((const float4*)sc.tangents)[i0];
   const float4 tq1 = ((const float4*)sc.tangents)[i1];
   const float4 tq2 = ((const float4*)sc.tangents)[i2];
-  const f3 tag = normalize3(mk3(tq0.x, tq0.y, tq0.z) * b.x + mk3(tq1.x, tq1.y, tq1.z) * b.y + mk3(tq2.x, tq2.y, tq2.z) * b.z);
-  f3 worldTag = normalize3(xformNormal(in, tag));
-  worldTag = normalize3(worldTag - dot3(worldTag, worldNrm) * worldNrm);
-  const f3 worldBin = tq0.w * cross3(worldNrm, worldTag);
-  const float tu = (b0.z * b.x + b1.z * b.y) + b2.z * b.z;
-  const float tv = (b0.w * b.x + b1.w * b.y) + b2.w * b.z;
-
-  // material: four aligned 16-byte loads of the padded record
+  // material: eight aligned 16-byte loads of the 128-byte record (factors + the four texture descriptors)
   const float4* mq = (const float4*)&sc.materials[matIndex];
   const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
+  const float4 d0 = mq[4], d1 = mq[5], d2 = mq[6], d3 = mq[7];
+  const DevInstance in = sc.instances[instId];
   GltfPBRMaterial mat;
   mat.pbrBaseColorFactor[0] = m0.x; mat.pbrBaseColorFactor[1] = m0.y; mat.pbrBaseColorFactor[2] = m0.z; mat.pbrBaseColorFactor[3] = m0.w;
   mat.pbrBaseColorTexture = __float_as_int(m1.x); mat.metallicFactor = m1.y; mat.roughnessFactor = m1.z;
   mat.metallicRoughnessTexture = __float_as_int(m1.w);
   mat.normalTexture = __float_as_int(m2.x); mat.emissiveFactor[0] = m2.y; mat.emissiveFactor[1] = m2.z; mat.emissiveFactor[2] = m2.w;
   mat.emissiveTexture = __float_as_int(m3.x);
+  const float tu = (b0.z * b.x + b1.z * b.y) + b2.z * b.z;
+  const float tv = (b0.w * b.x + b1.w * b.y) + b2.w * b.z;
+
+  // The four texture() calls of rchit:83-113 (emissive, normal, base colour, metallic-roughness): footprints first, then
+  // all sixteen texel loads, then the decode, so the loads overlap instead of forming four dependent round trips.
+  // A tap the reference would not issue reads texel 0 and is discarded.
+  const bool emits = prd.depth == 0 || prd.isSpecular;  // rchit:83
+  const bool wantE = emits && mat.emissiveTexture > -1, wantN = mat.normalTexture > -1;
+  const bool wantB = mat.pbrBaseColorTexture > -1, wantM = mat.metallicRoughnessTexture > -1;
+  st.taps += (wantE ? 1u : 0u) + (wantN ? 1u : 0u) + (wantB ? 1u : 0u) + (wantM ? 1u : 0u);
+  TexTap tE, tN, tB, tM;
+#define VKRT_FOOTPRINT(q, want, tap)                                                                                                   \
+  texFootprint(__float_as_uint(q.x), __float_as_uint(q.y) & 0xffffu, __float_as_uint(q.y) >> 16, (__float_as_uint(q.z) & 2u) != 0u,     \
+               (__float_as_uint(q.z) & 1u) != 0u, want, tu, tv, tap)
+  VKRT_FOOTPRINT(d3, wantE, tE);
+  VKRT_FOOTPRINT(d2, wantN, tN);
+  VKRT_FOOTPRINT(d0, wantB, tB);
+  VKRT_FOOTPRINT(d1, wantM, tM);
+#undef VKRT_FOOTPRINT
+  const uint32_t* __restrict__ tex = sc.texels;
+  const uint32_t e00 = tex[tE.i00], e10 = tex[tE.i10], e01 = tex[tE.i01], e11 = tex[tE.i11];
+  const uint32_t n00 = tex[tN.i00], n10 = tex[tN.i10], n01 = tex[tN.i01], n11 = tex[tN.i11];
+  const uint32_t c00 = tex[tB.i00], c10 = tex[tB.i10], c01 = tex[tB.i01], c11 = tex[tB.i11];
+  const uint32_t r00 = tex[tM.i00], r10 = tex[tM.i10], r01 = tex[tM.i01], r11 = tex[tM.i11];
+
+  const f3 pos = mk3(a0.x, a0.y, a0.z) * b.x + mk3(a1.x, a1.y, a1.z) * b.y + mk3(a2.x, a2.y, a2.z) * b.z;
+  const f3 worldPos = xformPoint(in, pos);
+  const f3 nrm = normalize3(mk3(a0.w, b0.x, b0.y) * b.x + mk3(a1.w, b1.x, b1.y) * b.y + mk3(a2.w, b2.x, b2.y) * b.z);
+  const f3 worldNrm = normalize3(xformNormal(in, nrm));
+  const f3 tag = normalize3(mk3(tq0.x, tq0.y, tq0.z) * b.x + mk3(tq1.x, tq1.y, tq1.z) * b.y + mk3(tq2.x, tq2.y, tq2.z) * b.z);
+  f3 worldTag = normalize3(xformNormal(in, tag));
+  worldTag = normalize3(worldTag - dot3(worldTag, worldNrm) * worldNrm);
+  const f3 worldBin = tq0.w * cross3(worldNrm, worldTag);
+
   f3 emittance = mk3(0.0f);
-  if(prd.depth == 0 || prd.isSpecular)  // rchit:83
+  if(emits)  // rchit:83
   {
     emittance = mk3(mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]);
-    if(mat.emissiveTexture > -1)
+    if(wantE)
     {
-      const f4 t = sampleTex(sc, mat.emissiveTexture, tu, tv, st);
+      const f4 t = texBlend(st.lut, tE, e00, e10, e01, e11);
       emittance = emittance * mk3(t.x, t.y, t.z);
     }
   }
   f3 tangent = worldTag, binormal = worldBin;
   f3 texNormal = worldNrm;
-  if(mat.normalTexture > -1)  // rchit:100-106
+  if(wantN)  // rchit:100-106
   {
-    const f4 t = sampleTex(sc, mat.normalTexture, tu, tv, st);
+    const f4 t = texBlend(st.lut, tN, n00, n10, n01, n11);
     texNormal = normalize3(mk3(t.x, t.y, t.z) * 2.0f - mk3(1.0f));
     texNormal = normalize3(tangent * texNormal.x + binormal * texNormal.y + worldNrm * texNormal.z);
     createCoordinateSystem(texNormal, tangent, binormal);
   }
-  const f3 baseColor = pbrGetBaseColor(sc, mat, tu, tv, st);
-  float metalness, roughness;
-  pbrGetMetallicRoughness(sc, mat, tu, tv, metalness, roughness, st);
+  f3 baseColor = mk3(mat.pbrBaseColorFactor[0], mat.pbrBaseColorFactor[1], mat.pbrBaseColorFactor[2]);  // gltf.glsl:26-32
+  if(wantB)
+  {
+    const f4 t = texBlend(st.lut, tB, c00, c10, c01, c11);
+    baseColor = baseColor * mk3(t.x, t.y, t.z);
+  }
+  float metalness = mat.metallicFactor, roughness = mat.roughnessFactor;  // gltf.glsl:34-45
+  if(wantM)
+  {
+    const f4 t = texBlend(st.lut, tM, r00, r10, r01, r11);
+    roughness *= t.y;
+    metalness *= t.z;
+  }
 
   const f3 rayOrigin = worldPos;
   f3 rayDirection;
@@ -322,6 +399,11 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
   prd.rayDirection = rayDirection;
   prd.hitValue = emittance;
   prd.weight = BRDF * cosTheta / pdf;
+}
+
+VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, f3 worldRayDir, Payload& prd, ShadeStats& st)
+{
+  closestHitShader(sc, pc, hit, sc.triShade[hit.slot], worldRayDir, prd, st);
 }
 
 // raytrace.rmiss:11-19

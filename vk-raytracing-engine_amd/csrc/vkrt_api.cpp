@@ -226,13 +226,6 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   for(uint32_t i = 0; i < d->prim_mesh_count; i++)
     lookup[i] = DevPrimInfo{PrimMeshInfo{d->prim_meshes[i].firstIndex, d->prim_meshes[i].vertexOffset, d->prim_meshes[i].materialIndex}, 0u};
   if((rc = upload(s, lookup.data(), lookup.size(), &D.primInfo)) != VKRT_OK) return bail(rc);
-  std::vector<DevMaterial> mats(d->material_count);
-  for(uint32_t i = 0; i < d->material_count; i++)
-  {
-    memset(&mats[i], 0, sizeof(DevMaterial));
-    mats[i].m = d->materials[i];
-  }
-  if((rc = upload(s, mats.data(), mats.size(), &D.materials)) != VKRT_OK) return bail(rc);
   // interleaved (position, normal, uv) records for the closest-hit attribute fetch (rchit:41-66)
   {
     std::vector<float> pn((size_t)d->vertex_count * 8);
@@ -273,16 +266,40 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
     pool.resize(at + n);
     memcpy(&pool[at], tx.rgba8, n * 4);
   }
-  float lut[256];
+  if(pool.empty())
+    pool.push_back(0xffffffffu);  // shading always issues its texel loads (to texel 0 when a material has no texture)
+  float lut[512];
   for(int i = 0; i < 256; i++)
   {
     const float c = (float)i / 255.0f;
     lut[i] = (c <= 0.04045f) ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
+    lut[256 + i] = c;
   }
+  // materials, with the descriptors of their textures folded in (DevMaterial)
+  std::vector<DevMaterial> mats(d->material_count);
+  for(uint32_t i = 0; i < d->material_count; i++)
+  {
+    memset(&mats[i], 0, sizeof(DevMaterial));
+    mats[i].m = d->materials[i];
+    const int idx[4] = {mats[i].m.pbrBaseColorTexture, mats[i].m.metallicRoughnessTexture, mats[i].m.normalTexture, mats[i].m.emissiveTexture};
+    for(int k = 0; k < 4; k++)
+    {
+      DevTexRef& r = mats[i].tex[k];
+      r = DevTexRef{0u, 1u | (1u << 16), 0u, 0u};
+      if(idx[k] >= 0 && (uint32_t)idx[k] < d->texture_count)
+      {
+        const DevTexture& t = table[(size_t)idx[k]];
+        if(t.width == 0u || t.height == 0u || t.width > 65535u || t.height > 65535u)
+          return bail(fail(VKRT_ERR_UNSUPPORTED, "texture %d is %ux%u (supported: 1..65535 per side)", idx[k], t.width, t.height));
+        r = DevTexRef{t.offset, t.width | (t.height << 16), 1u | (t.srgb ? 2u : 0u), 0u};
+      }
+    }
+  }
+  if((rc = upload(s, mats.data(), mats.size(), &D.materials)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, table.data(), table.size(), &D.textures)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, pool.data(), pool.size(), &D.texels)) != VKRT_OK) return bail(rc);
   const float* lutDev = nullptr;
-  if((rc = upload(s, lut, 256, &lutDev)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, lut, 512, &lutDev)) != VKRT_OK) return bail(rc);
   D.srgbLut = lutDev;
   D.textureCount = d->texture_count;
   D.rootRef = VKRT_TRAV_DONE;

@@ -37,7 +37,7 @@
 #define WF_BLOCK 256
 
 // ---- path state in HBM: one 192-byte record per path (three 64-byte lines) ---------------------------------------
-//   line 0: Q0 ray origin.xyz, tmax | Q1 ray direction.xyz, anyHit | Q2 hit t,u,v,slot | Q3 unused
+//   line 0: Q0 ray origin.xyz, tmax | Q1 ray direction.xyz, anyHit | Q2 hit t,u,v,slot | Q3 triShade[slot] (closest hits)
 //   line 1: Q4 rayOrigin.xyz, lightDist | Q5 rayDirection.xyz, seed | Q6 shadowRayDir.xyz, flags | Q7 prd.hitValue.xyz, px|lrow
 //   line 2: Q8 prd.weight.xyz | Q9 curWeight.xyz | Q10 hitValue.xyz | Q11 hitValues.xyz
 // Traversal touches line 0 only; queue order gets scrambled by the per-type compaction, so records (not SoA
@@ -204,6 +204,12 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
     traverse_any<COUNT, WIDE>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit,
                               tc);
     r[2] = make_float4(hit.t, hit.u, hit.v, __int_as_float(hit.slot));
+    if(!anyHit && hit.slot >= 0)
+    {
+      // first hop of the hit shader's attribute fetch, taken here so k_wf_shade_closest finds it in the line it reads anyway
+      const uint4 ts = P.sc.triShade[hit.slot];
+      r[3] = make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w));
+    }
     nRays = 1;
   }
   __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (TB / 64)];
@@ -333,8 +339,10 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_closest(const TraceParams
   if(blockIdx.x * WF_BLOCK >= count)
     return;
   const unsigned qi = blockIdx.x * WF_BLOCK + threadIdx.x;
+  __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
+  st.lut = ldsTexelLut(P.sc, lut);
   __shared__ unsigned wsum[2 * (WF_BLOCK / 64 + 1)];
   bool toClosest = false, toShadow = false;
   unsigned pid = 0;
@@ -343,10 +351,11 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_closest(const TraceParams
     pid = qPtr(B, par, 0)[qi];
     LaneState L;
     loadState(P, B, pid, L);
-    const float4 h = rec(B, pid)[2];
+    const float4 h = rec(B, pid)[2], t4 = rec(B, pid)[3];
     RayHit hit;
     hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.slot = __float_as_int(h.w);
-    if(afterClosestRay(P, L, hit, L.prd.rayDirection, st))
+    const uint4 ts = make_uint4(__float_as_uint(t4.x), __float_as_uint(t4.y), __float_as_uint(t4.z), __float_as_uint(t4.w));
+    if(afterClosestRay(P, L, hit, ts, L.prd.rayDirection, st))
       toShadow = true;
     else
       toClosest = accumulateAndAdvance(P, L, false);
