@@ -127,11 +127,10 @@ struct TraceParams
   DevCounters* counters;
 };
 
-// Wavefront-mode working set (wavefront.hip): per-path SoA state, ray / hit records, two queues.
+// Wavefront-mode working set (wavefront.hip): four record streams [parity][type] of SoA float4 planes + their counts.
 struct WfBuffers
 {
-  unsigned* ctrl;       // queue counts [parity*2 + type], type 0 = closest-hit rays, 1 = shadow rays
-  float4* rec;          // 12 float4 (192 B) per path: ray + hit | state | state (wavefront.hip)
-  unsigned* queue[4];   // path ids, [parity*2 + type]
-  uint32_t capacity;    // paths
+  unsigned* ctrl;       // stream counts [parity*2 + type], type 0 = closest-hit rays, 1 = shadow rays
+  float4* planes;       // [parity*2 + type][plane][capacity]
+  uint32_t capacity;    // paths (pixels of the shard, rounded up to whole 8x8 tiles)
 };

@@ -100,17 +100,24 @@ VKRT_DEV bool afterClosestRay(const TraceParams& P, LaneState& L, const RayHit& 
   return false;
 }
 
+// raytrace.rgen:99-102,115 -- the two products of a finished segment: its clamped radiance contribution and the path
+// weight after it.  Split from the bookkeeping below so the wavefront pipeline can carry (contrib, nextWeight) across
+// the shadow ray instead of (prd.hitValue, curWeight, prd.weight); the float operations are the same.
+VKRT_DEV void segmentTerms(const LaneState& L, f3& contrib, f3& nextWeight)
+{
+  const f3 q = L.prd.hitValue * L.curWeight;
+  contrib = mk3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
+  nextWeight = L.curWeight * L.prd.weight;
+}
+
 // raytrace.rgen:99-120 -- accumulate the segment, advance depth / sample.  Returns false when the
 // pixel is complete (its value has been stored).
-VKRT_DEV bool accumulateAndAdvance(const TraceParams& P, LaneState& L, bool shadowHit)
+VKRT_DEV bool advanceSegment(const TraceParams& P, LaneState& L, bool shadowHit, f3 contrib, f3 nextWeight)
 {
   L.stage = 0;
   if(!shadowHit)  // rgen:99-102
-  {
-    const f3 q = L.prd.hitValue * L.curWeight;
-    L.hitValue = L.hitValue + mk3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
-  }
-  L.curWeight = L.curWeight * L.prd.weight;  // rgen:115
+    L.hitValue = L.hitValue + contrib;
+  L.curWeight = nextWeight;  // rgen:115
   L.prd.depth++;
   if(!(L.prd.depth < (uint32_t)P.pc.depth))
   {
@@ -125,4 +132,11 @@ VKRT_DEV bool accumulateAndAdvance(const TraceParams& P, LaneState& L, bool shad
     }
   }
   return true;
+}
+
+VKRT_DEV bool accumulateAndAdvance(const TraceParams& P, LaneState& L, bool shadowHit)
+{
+  f3 contrib, nextWeight;
+  segmentTerms(L, contrib, nextWeight);
+  return advanceSegment(P, L, shadowHit, contrib, nextWeight);
 }

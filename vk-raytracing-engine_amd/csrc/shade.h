@@ -244,12 +244,11 @@ VKRT_DEV f3 xformNormal(const DevInstance& in, f3 n)
 // raytrace.rchit:31-219
 // `ts` = sc.triShade[hit.slot] (vertex indices + material), fetched by the caller (the wavefront traversal kernel
 // leaves it in the path record next to the hit).
-VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, const uint4 ts, f3 worldRayDir, Payload& prd,
-                               ShadeStats& st)
+// `instId` = the instance the hit triangle belongs to (third word of its last triangle-record quad).  hit.slot is not read.
+VKRT_DEV void closestHitShaderInst(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, const uint32_t instId, const uint4 ts,
+                                   f3 worldRayDir, Payload& prd, ShadeStats& st)
 {
   st.hits++;
-  const float4 rec = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
-  const uint32_t instId = (uint32_t)__float_as_int(rec.z);
   // rchit:34-50 (PrimMeshInfo lookup, three index fetches, vertexOffset, max(0, materialIndex)) is resolved once
   // per triangle at build time into a 16-byte record, so the attribute fetch below is one hop from the hit.
   const uint32_t i0 = ts.x, i1 = ts.y, i2 = ts.z, matIndex = ts.w;
@@ -401,6 +400,12 @@ VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, co
   prd.weight = BRDF * cosTheta / pdf;
 }
 
+VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, const uint4 ts, f3 worldRayDir, Payload& prd,
+                               ShadeStats& st)
+{
+  const uint32_t instId = (uint32_t)__float_as_int(sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
+  closestHitShaderInst(sc, pc, hit, instId, ts, worldRayDir, prd, st);
+}
 VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, f3 worldRayDir, Payload& prd, ShadeStats& st)
 {
   closestHitShader(sc, pc, hit, sc.triShade[hit.slot], worldRayDir, prd, st);
