@@ -67,3 +67,21 @@ def test_shard_rows_math():
                 assert rows == len(shard_row_indices(H, world, rank))
                 total += rows
             assert total == H
+
+
+def test_ctypes_mirror_matches_header_struct_sizes(tmp_path):
+    """abi.py restates include/vkrt.h by hand: compile the header and compare sizeof of every struct the harness passes."""
+    pairs = {"vkrt_prim_mesh": abi.PrimMesh, "vkrt_node": abi.Node, "vkrt_texture": abi.Texture, "vkrt_scene_desc": abi.SceneDesc,
+             "vkrt_shard": abi.Shard, "vkrt_trace_opts": abi.TraceOpts, "vkrt_counters": abi.Counters, "vkrt_accel_info": abi.AccelInfo,
+             "vkrt_gbuffer": abi.Gbuffer, "vkrt_trace_timing": abi.TraceTiming, "GlobalUniforms": abi.GlobalUniforms,
+             "PushConstantRay": abi.PushConstantRay, "PushConstantPost": abi.PushConstantPost, "GltfPBRMaterial": abi.GltfPBRMaterial,
+             "GltfLight": abi.GltfLight, "PrimMeshInfo": abi.PrimMeshInfo}
+    body = "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs)
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "vkrt.h"\nint main(void){\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    for name, ct in pairs.items():
+        assert int(got[name]) == C.sizeof(ct), (name, got[name], C.sizeof(ct))

@@ -238,6 +238,17 @@ def test_cli_renders_config_json(tmp_path, small_atrium):
     pfm = (tmp_path / "out.pfm").read_bytes()
     assert pfm.startswith(b"PF\n96 54\n-1.0\n") and len(pfm) == len(b"PF\n96 54\n-1.0\n") + 96 * 54 * 12
     assert (tmp_path / "out.ppm").read_bytes().startswith(b"P6\n96 54\n255\n")
+    # display image = post.frag (pass-through + gamma 1/2.2) of the radiance image, as 8-bit PNG
+    from PIL import Image
+
+    import imgdiff
+
+    lin, _ = imgdiff.read_image(str(tmp_path / "out.pfm"))
+    png = np.asarray(Image.open(tmp_path / "out.png"), np.float32)
+    assert png.shape == (54, 96, 4) and np.all(png[..., 3] == 255)
+    want = np.clip(np.clip(lin, 0, None) ** (1 / 2.2), 0, 1) * 255
+    assert np.abs(png[..., :3] - want).max() <= 1.0
+    assert imgdiff.main([str(tmp_path / "out.pfm"), str(tmp_path / "out.pfm"), "--out", str(tmp_path / "d.png")])["rmse"] == 0.0
 
 
 @pytest.mark.gpu
@@ -278,3 +289,65 @@ def test_cli_hybrid_mode_matches_oracle(tmp_path, small_atrium):
     want = g["color"][..., :3] * acc[..., 3:4] + acc[..., :3]
     bad = np.abs(img - want) > 1e-4 * (1 + np.abs(want))
     assert bad.any(axis=-1).mean() < 2e-3
+
+
+def test_jpeg_texture_through_sidecar_prepass(tmp_path):
+    """JPEG images reach the loader through tools/decode_textures.py (.rgba8 sidecar); the loader reports
+    without it the loader substitutes the reference's 1x1 white dummy."""
+    from PIL import Image
+
+    import decode_textures
+
+    rng = np.random.default_rng(5)
+    img = np.kron(rng.integers(0, 256, (4, 6, 3), dtype=np.uint8), np.ones((8, 8, 1), np.uint8))  # blocky: JPEG-friendly
+    Image.fromarray(img, "RGB").save(tmp_path / "albedo.jpg", quality=95)
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    (tmp_path / "tri.bin").write_bytes(pos.tobytes() + np.array([0, 1, 2], np.uint32).tobytes())
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
+           "textures": [{"source": 0}], "images": [{"uri": "albedo.jpg"}],
+           "buffers": [{"uri": "tri.bin", "byteLength": 48}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 12}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3", "min": [0, 0, 0], "max": [1, 1, 0]},
+                         {"bufferView": 1, "componentType": 5125, "count": 3, "type": "SCALAR"}]}
+    path = tmp_path / "tri.gltf"
+    path.write_text(json.dumps(doc))
+    flat = host_py.load_gltf(str(path))  # no sidecar yet: the reference's rule for an undecodable image, 1x1 white (hello_vulkan.cpp:487-491)
+    assert flat.textures[0]["rgba8"].shape == (1, 1, 4) and np.all(flat.textures[0]["rgba8"] == 255)
+    assert decode_textures.main([str(path)]) == 0
+    flat = host_py.load_gltf(str(path))
+    want = np.array(Image.open(tmp_path / "albedo.jpg").convert("RGBA"), np.uint8)
+    assert len(flat.textures) == 1 and flat.textures[0]["is_srgb"]  # base colour => sRGB (hello_vulkan.cpp:417-443)
+    assert np.array_equal(flat.textures[0]["rgba8"], want)
+    assert np.abs(want[..., :3].astype(int) - img.astype(int)).mean() < 16  # it really is the picture (JPEG is lossy at block edges)
+
+
+def test_png_writer_round_trip(tmp_path):
+    """the display image (post.frag output) as an 8-bit PNG; read back with PIL and with the native decoder."""
+    from PIL import Image
+
+    rng = np.random.default_rng(9)
+    disp = rng.uniform(-0.1, 1.1, (37, 53, 4)).astype(np.float32)
+    disp[0, 0] = [0.0, 1.0, 0.5, 1.0]
+    path = str(tmp_path / "d.png")
+    host_py.write_png(path, disp)
+    want = (np.clip(disp, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    assert np.array_equal(np.array(Image.open(path)), want)
+    assert np.array_equal(host_py.decode_png(open(path, "rb").read()), want)
+
+
+def test_imgdiff_tool(tmp_path):
+    import imgdiff
+
+    rng = np.random.default_rng(3)
+    a = rng.uniform(0, 1, (20, 30, 3)).astype(np.float32)
+    b = a.copy()
+    b[5, 7] += 0.5
+    np.save(tmp_path / "a.npy", a)
+    np.save(tmp_path / "b.npy", b)
+    st = imgdiff.main([str(tmp_path / "a.npy"), str(tmp_path / "b.npy"), "--out", str(tmp_path / "d.png")])
+    assert abs(st["max_abs"] - 0.5) < 1e-6 and abs(st["pixels_differing"] - 1 / 600) < 1e-9
+    from PIL import Image
+
+    assert Image.open(tmp_path / "d.png").size == (90, 20)

@@ -125,4 +125,18 @@ int vkrt_host_decode_png(const uint8_t* data, uint64_t size, uint32_t* wh, uint8
   return 0;
 }
 
+int vkrt_host_write_png(const char* path, const float* displayRgba, int w, int h)
+{
+  try
+  {
+    writePNG(path, std::vector<float>(displayRgba, displayRgba + (size_t)w * h * 4), w, h);
+    return 0;
+  }
+  catch(const std::exception& e)
+  {
+    g_err = e.what();
+    return 1;
+  }
+}
+
 }  // extern "C"

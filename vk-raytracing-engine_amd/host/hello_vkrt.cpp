@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <zlib.h>
 #include <sstream>
 #include <stdexcept>
 
@@ -267,6 +268,50 @@ void writePPM(const std::string& path, const std::vector<float>& rgba, int w, in
       }
     f.write((const char*)row.data(), (std::streamsize)row.size());
   }
+}
+
+// 8-bit RGBA PNG of a display image (values already through post.frag's gamma, [0,1]); zlib does deflate + CRC
+void writePNG(const std::string& path, const std::vector<float>& displayRgba, int w, int h)
+{
+  std::vector<unsigned char> raw((size_t)h * ((size_t)w * 4 + 1));
+  for(int y = 0; y < h; y++)
+  {
+    unsigned char* row = &raw[(size_t)y * ((size_t)w * 4 + 1)];
+    row[0] = 0;  // filter: none
+    for(int x = 0; x < w * 4; x++)
+    {
+      const float v = displayRgba[(size_t)y * w * 4 + x];
+      row[1 + x] = (unsigned char)(std::fmin(std::fmax(v, 0.0f), 1.0f) * 255.0f + 0.5f);
+    }
+  }
+  uLongf zlen = compressBound((uLong)raw.size());
+  std::vector<unsigned char> z(zlen);
+  if(compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK)
+    throw std::runtime_error("writePNG: deflate failed");
+  std::ofstream f(path, std::ios::binary);
+  auto be32 = [](unsigned char* p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; };
+  auto chunk = [&](const char* tag, const unsigned char* data, size_t n) {
+    unsigned char hd[8];
+    be32(hd, (uint32_t)n);
+    memcpy(hd + 4, tag, 4);
+    f.write((const char*)hd, 8);
+    if(n) f.write((const char*)data, (std::streamsize)n);
+    uLong c = crc32(0L, (const Bytef*)tag, 4);
+    if(n) c = crc32(c, data, (uInt)n);
+    unsigned char cr[4];
+    be32(cr, (uint32_t)c);
+    f.write((const char*)cr, 4);
+  };
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  f.write((const char*)sig, 8);
+  unsigned char ihdr[13];
+  be32(ihdr, (uint32_t)w); be32(ihdr + 4, (uint32_t)h);
+  ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8-bit RGBA, deflate, no filter method / interlace
+  chunk("IHDR", ihdr, 13);
+  chunk("IDAT", z.data(), zlen);
+  chunk("IEND", nullptr, 0);
+  if(!f)
+    throw std::runtime_error("writePNG: cannot write " + path);
 }
 
 void writePFM(const std::string& path, const std::vector<float>& rgba, int w, int h)

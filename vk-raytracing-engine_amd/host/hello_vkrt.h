@@ -116,6 +116,7 @@ AppConfig loadConfig(const std::string& path);
 
 // post.frag:39,58 -- gamma 1/2.2 on all four channels; writers for review images
 void writePPM(const std::string& path, const std::vector<float>& rgba, int w, int h);
+void writePNG(const std::string& path, const std::vector<float>& displayRgba, int w, int h);  // display image (post.frag output)
 void writePFM(const std::string& path, const std::vector<float>& rgba, int w, int h);
 
 }  // namespace vkrt_host

@@ -84,11 +84,11 @@ int main(int argc, char** argv)
     const std::string out = !outOverride.empty() ? outOverride : cfg.output;
     if(!out.empty())
     {
-      std::vector<float> img;
+      std::vector<float> img, display;
+      helloVk.drawPost(display);                                // main.cpp:605-612: what the window would show
+      writePNG(out + ".png", display, cfg.width, cfg.height);
       if(hybrid)
       {  // composite of the raster plane and the ray-traced plane (post.frag:41-47), before gamma for the PFM
-        std::vector<float> display;
-        helloVk.drawPost(display);
         img.resize(display.size());
         for(size_t k = 0; k < display.size(); k++) img[k] = std::pow(display[k], 2.2f);
       }
@@ -96,7 +96,7 @@ int main(int argc, char** argv)
         helloVk.downloadImage(img);
       writePFM(out + ".pfm", img, cfg.width, cfg.height);
       writePPM(out + ".ppm", img, cfg.width, cfg.height);
-      printf("wrote %s.pfm / %s.ppm\n", out.c_str(), out.c_str());
+      printf("wrote %s.pfm / %s.ppm / %s.png\n", out.c_str(), out.c_str(), out.c_str());
     }
   }
   catch(const std::exception& e)

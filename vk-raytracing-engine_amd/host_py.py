@@ -34,6 +34,8 @@ def lib():
         L.vkrt_host_render_gltf.restype = C.c_int
         L.vkrt_host_decode_png.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
         L.vkrt_host_decode_png.restype = C.c_int
+        L.vkrt_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        L.vkrt_host_write_png.restype = C.c_int
         _lib = L
     return _lib
 
@@ -104,3 +106,10 @@ def decode_png(data):
     out = np.zeros((int(wh[1]), int(wh[0]), 4), np.uint8)
     lib().vkrt_host_decode_png(buf.ctypes.data, buf.size, wh.ctypes.data, out.ctypes.data, out.size)
     return out
+
+
+def write_png(path, display_rgba):
+    """8-bit RGBA PNG of a display image (float32 [H,W,4] in [0,1], i.e. after post.frag's gamma)."""
+    a = np.ascontiguousarray(display_rgba, np.float32)
+    if lib().vkrt_host_write_png(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0]) != 0:
+        raise RuntimeError(lib().vkrt_host_last_error().decode())
