@@ -21,6 +21,12 @@ for spp, depth in ((1, 1), (1, 8), (4, 8)):
         torch.cuda.synchronize()
         t = r.last_trace_timing(); c = r.counters()
     rays = c["rays_closest"] + c["rays_shadow"]
+    free = []
+    for it in range(4):  # untimed kernels: the sub-frame pipeline (VKRT_WF_SUBFRAMES) is active
+        r.pathtrace(pc, cam, W, H, seed=1, flags=0, image=img)
+        torch.cuda.synchronize()
+        free.append(r.last_trace_ms())
+    frame_ms = min(free[1:])
     r.reset_counters()
     r.pathtrace(pc, cam, W, H, seed=1, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL, image=img)
     cc = r.counters()
@@ -30,5 +36,5 @@ for spp, depth in ((1, 1), (1, 8), (4, 8)):
             "tri_lane_eff": round(cc["tris_tested"] / max(64 * cc["wave_tri_steps"], 1), 3),
             "wave_node_steps": cc["wave_node_steps"], "wave_tri_steps": cc["wave_tri_steps"]}
     print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("VKRT_")}, "spp": spp, "depth": depth, "rays": rays,
-                      "total_ms": round(t["total_ms"], 3), "traverse_ms": round(t["traverse_ms"], 3), "launches": t["traverse_launches"],
+                      "frame_ms": round(frame_ms, 3), "Mrays_s_frame": round(rays / frame_ms / 1e3, 1), "total_ms": round(t["total_ms"], 3), "traverse_ms": round(t["traverse_ms"], 3), "launches": t["traverse_launches"],
                       "Mrays_s_total": round(rays / t["total_ms"] / 1e3, 1), "Mrays_s_traverse": round(rays / max(t["traverse_ms"], 1e-9) / 1e3, 1), "mode": t["mode"], **work}))

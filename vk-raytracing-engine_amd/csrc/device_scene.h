@@ -122,6 +122,7 @@ struct TraceParams
   uint32_t stripRows, shardCount, shardIndex;
   uint32_t localRows;       // rows in this shard's buffer
   uint32_t tilesX, tileCount;
+  uint32_t tileFirst;       // wavefront mode: first 8x8 tile of this launch's sub-frame (0 elsewhere)
   float* image;             // rgba32f, localRows x fullW
   unsigned int* workCounter;
   DevCounters* counters;

@@ -17,9 +17,20 @@ struct WfTiming
   int capacity;
   int used;             // pairs recorded around k_wf_traverse launches
 };
+// Sub-frames: the tiles of a frame are split into up to VKRT_WF_MAX_SUBFRAMES independent groups, each with its own
+// streams, driven from its own HIP stream so that the kernels of different groups overlap (the VALU-bound traversal of
+// one group runs beside the memory-bound shading of another, and kernel tails are filled).
+#define VKRT_WF_MAX_SUBFRAMES 8
+struct WfAsync
+{
+  hipStream_t streams[VKRT_WF_MAX_SUBFRAMES];  // internal streams (created by the caller of vkrt_launch_wavefront)
+  hipEvent_t fork, join[VKRT_WF_MAX_SUBFRAMES];
+  int count;                                    // usable entries (0/1 = everything on the caller's stream)
+};
 size_t     vkrt_wf_state_bytes(uint32_t pathCapacity);
 void       vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B);
-hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing);
+hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing,
+                                 const WfAsync* async);
 
 // hybrid mode (hybrid.hip)
 hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], int lightsCount, float* color, float* position, float* normal,

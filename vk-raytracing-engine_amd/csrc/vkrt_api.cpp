@@ -74,6 +74,7 @@ struct vkrt_scene
   // wavefront mode working set
   void* wfMem = nullptr;
   WfBuffers wf{};
+  WfAsync wfAsync{};
   std::vector<hipEvent_t> wfEvents;
   WfTiming wfTiming{};
   bool wfTimed = false;
@@ -330,6 +331,15 @@ void vkrt_scene_destroy(vkrt_scene* s)
   for(void* p : s->allocs)
     (void)hipFree(p);
   if(s->wfMem) (void)hipFree(s->wfMem);
+  if(s->wfAsync.count)
+  {
+    (void)hipEventDestroy(s->wfAsync.fork);
+    for(int j = 0; j < s->wfAsync.count; j++)
+    {
+      (void)hipStreamDestroy(s->wfAsync.streams[j]);
+      (void)hipEventDestroy(s->wfAsync.join[j]);
+    }
+  }
   for(hipEvent_t e : s->wfEvents) (void)hipEventDestroy(e);
   if(s->evStart) (void)hipEventDestroy(s->evStart);
   if(s->evStop) (void)hipEventDestroy(s->evStop);
@@ -593,6 +603,7 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   if(tiles * 64 >= 0xFFFFFFFFull)
     return fail(VKRT_ERR_UNSUPPORTED, "launch too large");
   P.tileCount = (uint32_t)tiles;
+  P.tileFirst = 0;
 
   const bool count = (P.flags & VKRT_TRACE_COUNT_TRAVERSAL) != 0;
   if(useWavefront())
@@ -624,7 +635,18 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
     }
     s->wfTimed = timing != nullptr;
     HIP_TRY(hipEventRecord(s->evStart, stream));
-    HIP_TRY(vkrt_launch_wavefront(P, s->wf, s->cuCount, count, stream, timing));
+    if(s->wfAsync.count == 0)
+    {
+      // internal streams for the sub-frame pipeline (wavefront.hip); created once per scene
+      HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.fork, hipEventDisableTiming));
+      for(int j = 0; j < VKRT_WF_MAX_SUBFRAMES; j++)
+      {
+        HIP_TRY(hipStreamCreateWithFlags(&s->wfAsync.streams[j], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.join[j], hipEventDisableTiming));
+      }
+      s->wfAsync.count = VKRT_WF_MAX_SUBFRAMES;
+    }
+    HIP_TRY(vkrt_launch_wavefront(P, s->wf, s->cuCount, count, stream, timing, &s->wfAsync));
     HIP_TRY(hipEventRecord(s->evStop, stream));
     s->timed = true;
     return VKRT_OK;
@@ -677,6 +699,7 @@ int fillParams(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* c
   if(tiles * 64 >= 0xFFFFFFFFull)
     return fail(VKRT_ERR_UNSUPPORTED, "launch too large");
   P.tileCount = (uint32_t)tiles;
+  P.tileFirst = 0;
   return VKRT_OK;
 }
 }  // namespace

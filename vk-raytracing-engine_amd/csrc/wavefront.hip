@@ -35,6 +35,7 @@
 #include "traverse_wide.h"
 
 #define WF_BLOCK 256
+#define VKRT_WF_SUBFRAMES_DEFAULT 2
 
 // ---- streams ---------------------------------------------------------------------------------------------------------
 // Four streams [parity][type] (type 0 = paths whose next ray is the closest-hit ray, 1 = the shadow ray), each
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_init(const TraceParams P, const
   LaneState L;
   if(w < P.tileCount * 64u)
   {
-    const unsigned tile = w >> 6, inTile = w & 63u;
+    const unsigned tile = P.tileFirst + (w >> 6), inTile = w & 63u;
     const uint32_t x = (tile % P.tilesX) * 8u + (inTile & 7u);
     const uint32_t lrow = (tile / P.tilesX) * 8u + (inTile >> 3);
     if(x < P.fullW && lrow < P.localRows)
@@ -220,14 +221,10 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
 }
 
 // ---- shade, closest-hit results: rchit / rmiss, then shadow request or accumulation (heavy; few waves/SIMD) ---------
-__global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_closest(const TraceParams P, const WfBuffers B, const int round)
+VKRT_DEV void shadeClosestBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
 {
   const unsigned lane = lane_id();
-  const int par = round & 1;
-  const unsigned count = B.ctrl[par * 2 + 0];
-  if(blockIdx.x * WF_BLOCK >= count)
-    return;
-  const unsigned qi = blockIdx.x * WF_BLOCK + threadIdx.x;
+  const unsigned qi = block * WF_BLOCK + threadIdx.x;
   __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
@@ -266,14 +263,10 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_closest(const TraceParams
 }
 
 // ---- shade, shadow results: accumulate the segment (rgen:99-120), next sample or pixel store (light; many waves) --------
-__global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_shadow(const TraceParams P, const WfBuffers B, const int round)
+VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
 {
   const unsigned lane = lane_id();
-  const int par = round & 1;
-  const unsigned count = B.ctrl[par * 2 + 1];
-  if(blockIdx.x * WF_BLOCK >= count)
-    return;
-  const unsigned qi = blockIdx.x * WF_BLOCK + threadIdx.x;
+  const unsigned qi = block * WF_BLOCK + threadIdx.x;
   __shared__ unsigned wsum[2 * (WF_BLOCK / 64 + 1)];
   bool toClosest = false;
   LaneState L;
@@ -292,24 +285,81 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_shadow(const TraceParams 
     storeClosest(B, par ^ 1, slot, L);
 }
 
+// One launch shades both result streams of a round: the heavy closest-hit workgroups are dispatched first, the light
+// shadow-result workgroups fill in behind them.
+__global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
+{
+  const int par = round & 1;
+  const unsigned countC = B.ctrl[par * 2 + 0], countS = B.ctrl[par * 2 + 1];
+  const unsigned nbC = (countC + WF_BLOCK - 1) / WF_BLOCK, nbS = (countS + WF_BLOCK - 1) / WF_BLOCK;
+  if(blockIdx.x >= nbC + nbS)
+    return;
+  if(blockIdx.x < nbC)
+    shadeClosestBlock(P, B, par, countC, blockIdx.x);
+  else
+    shadeShadowBlock(P, B, par, countS, blockIdx.x - nbC);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 size_t vkrt_wf_state_bytes(uint32_t pathCapacity)
 {
-  return (size_t)pathCapacity * 4 * WF_PLANES * sizeof(float4) + 256;
+  return (size_t)pathCapacity * 4 * WF_PLANES * sizeof(float4) + 256 * VKRT_WF_MAX_SUBFRAMES;
 }
 
 void vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B)
 {
   char* p = (char*)base;
-  B->ctrl = (unsigned*)p;
-  p += 256;
+  B->ctrl = (unsigned*)p;  // 256 bytes of counts per sub-frame
+  p += 256 * VKRT_WF_MAX_SUBFRAMES;
   B->planes = (float4*)p;
   B->capacity = pathCapacity;
 }
 
-hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing)
+static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, bool count, hipStream_t stream, WfTiming* timing);
+
+hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing,
+                                 const WfAsync* async)
 {
   (void)cuCount;
+  static int want = -1;
+  if(want < 0)
+  {
+    const char* ev = getenv("VKRT_WF_SUBFRAMES");
+    want = ev ? atoi(ev) : VKRT_WF_SUBFRAMES_DEFAULT;
+    want = std::max(1, std::min(VKRT_WF_MAX_SUBFRAMES, want));
+  }
+  // per-kernel timing wants the kernels one after another; tiny frames are not worth splitting
+  int n = (timing || !async) ? 1 : std::min(want, async->count);
+  n = (int)std::min<uint32_t>((uint32_t)std::max(n, 1), std::max(1u, P.tileCount / 256u));
+  if(n <= 1)
+  {
+    TraceParams Q = P;
+    Q.tileFirst = 0;
+    return launchSubframe(Q, B, count, stream, timing);
+  }
+  hipError_t e = hipEventRecord(async->fork, stream);
+  if(e != hipSuccess)
+    return e;
+  for(int j = 0; j < n; j++)
+  {
+    const uint32_t t0 = (uint32_t)((uint64_t)P.tileCount * j / n), t1 = (uint32_t)((uint64_t)P.tileCount * (j + 1) / n);
+    TraceParams Q = P;
+    Q.tileFirst = t0;
+    Q.tileCount = t1 - t0;
+    WfBuffers Bj;
+    Bj.ctrl = B.ctrl + 64 * j;
+    Bj.planes = B.planes + (size_t)4 * WF_PLANES * ((size_t)t0 * 64u);
+    Bj.capacity = Q.tileCount * 64u;
+    if((e = hipStreamWaitEvent(async->streams[j], async->fork, 0)) != hipSuccess) return e;
+    if((e = launchSubframe(Q, Bj, count, async->streams[j], nullptr)) != hipSuccess) return e;
+    if((e = hipEventRecord(async->join[j], async->streams[j])) != hipSuccess) return e;
+    if((e = hipStreamWaitEvent(stream, async->join[j], 0)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, bool count, hipStream_t stream, WfTiming* timing)
+{
   const unsigned work = P.tileCount * 64u;
   hipError_t e = hipMemsetAsync(B.ctrl, 0, 64, stream);
   if(e != hipSuccess)
@@ -362,8 +412,7 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int c
       (void)hipEventRecord(timing->events[2 * timing->used + 1], stream);
       timing->used++;
     }
-    hipLaunchKernelGGL(k_wf_shade_closest, dim3(blocks), bb, 0, stream, P, B, r);
-    hipLaunchKernelGGL(k_wf_shade_shadow, dim3(blocks), bb, 0, stream, P, B, r);
+    hipLaunchKernelGGL(k_wf_shade, dim3(blocks + 2), bb, 0, stream, P, B, r);
   }
   return hipGetLastError();
 }
