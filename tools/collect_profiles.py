@@ -8,11 +8,20 @@ src = os.path.join(ROOT, "gpurun_out", "final")
 prof = os.path.join(ROOT, "profiles")
 line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith("{")][-1]
 open(os.path.join(prof, f"{tag}_bench.json"), "w").write(line)
-shutil.copy(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0], os.path.join(prof, f"{tag}_kernel_stats.csv"))
+
+
+def newest(pattern):
+    """gpurun merges new files into gpurun_out/ without deleting those of earlier calls: take the latest."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+shutil.copy(newest(os.path.join(src, "stats", "*", "*kernel_stats.csv")), os.path.join(prof, f"{tag}_kernel_stats.csv"))
+if glob.glob(os.path.join(src, "stats_pipelined", "*", "*kernel_stats.csv")):
+    shutil.copy(newest(os.path.join(src, "stats_pipelined", "*", "*kernel_stats.csv")), os.path.join(prof, f"{tag}_kernel_stats_pipelined.csv"))
 
 
 def per_kernel(dirname, counter):
-    f = glob.glob(os.path.join(src, dirname, "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(src, dirname, "*", "*counter_collection.csv"))
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -43,4 +52,19 @@ if dom:
     out["hbm_bytes_per_launch"] = out["kernels"][dom]["read_bytes_per_launch_x2"] + out["kernels"][dom]["write_bytes_per_launch"]
     out["hbm_bytes_per_launch_raw"] = out["kernels"][dom]["read_bytes_per_launch_raw"] + out["kernels"][dom]["write_bytes_per_launch"]
 json.dump(out, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+# VALU issue rate of the dominant kernel (the resource that actually binds it): wave-instructions per launch
+if glob.glob(os.path.join(src, "pmc_valu", "*", "*counter_collection.csv")):
+    valu, nv = per_kernel("pmc_valu", "SQ_INSTS_VALU")
+    waves, _ = per_kernel("pmc_valu", "SQ_WAVES")
+    issue = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES (kernel-trace only, VKRT_WF_SUBFRAMES=1) on `python3 bench.py --no-cpu-baseline`",
+             "unit": "VALU wave-instructions", "kernels": {}}
+    for k in valu:
+        if k.strip().startswith(("void k_wf", "k_wf")):
+            issue["kernels"][k.strip()] = {"launches_profiled": nv[k], "valu_wave_instr_per_launch": valu[k] / max(nv[k], 1),
+                                           "waves_per_launch": waves.get(k, 0.0) / max(nv[k], 1)}
+    d = next((k for k in issue["kernels"] if "traverse" in k), None)
+    if d:
+        issue["dominant_kernel"] = d
+        issue["valu_wave_instr_per_launch"] = issue["kernels"][d]["valu_wave_instr_per_launch"]
+    json.dump(issue, open(os.path.join(prof, "pmc_issue.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])

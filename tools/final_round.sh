@@ -10,8 +10,14 @@ step pytest 600 python -m pytest tests -m gpu -q
 step bench 600 python bench.py
 export TMPDIR=/tmp
 cd /tmp
+# per-kernel durations that bench.py's roofline must agree with are those of un-overlapped launches: one sub-frame
+export VKRT_WF_SUBFRAMES=1
 step stats 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline
+step pmc_valu 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_valu -- python3 $R/bench.py --no-cpu-baseline
 step pmc_fetch 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --no-cpu-baseline
 step pmc_write 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --no-cpu-baseline
+unset VKRT_WF_SUBFRAMES
+# the default configuration (two sub-frames on internal streams: kernels overlap, durations are not exclusive)
+step stats_pipelined 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $R/bench.py --no-cpu-baseline
 cd $R
 tail -3 $OUT/pytest.log; tail -1 $OUT/bench.log | cut -c1-400; cat $OUT/stats/*/*kernel_stats.csv | cut -c1-150 | head -6
