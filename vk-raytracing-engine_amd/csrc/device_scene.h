@@ -97,12 +97,14 @@ struct DevScene
   uint32_t layout;            // 0 = BVH2 (64-B nodes), 1 = wide8 (80-B compressed nodes)
   uint32_t stepLimit;         // traversal step bound (termination safety net)
   uint32_t triThreshold;      // wide8: lanes with pending triangles needed before a wave tests them (0 = test at once)
+  uint32_t sharePeriodMask;   // work sharing is attempted on steps with (step & mask) == mask (0 = every step)
+  uint32_t shareMinIdle;      // wide8, wavefront mode: idle lanes of a wave take over pending subtrees of busy lanes once this many are idle (0 = off)
 };
 
 // Counter storage: 64 slots of 10 counters (padded to two 64-byte lines, order of vkrt_counters).  A workgroup
 // adds its block-reduced totals to slot (blockIdx % 64), so same-address atomic serialisation is
 // 64x lower than with one set of counters; vkrt_counters_read sums the slots.
-#define VKRT_W8_MAX_POSTPONED 4  // parked triangle groups per lane (traverse_wide.h)
+#define VKRT_W8_MAX_POSTPONED 2  // parked triangle groups per lane (traverse_wide.h)
 
 #define VKRT_COUNTER_SLOTS 64
 struct DevCounters

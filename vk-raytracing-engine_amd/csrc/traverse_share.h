@@ -1,0 +1,251 @@
+// traverse_share.h -- wide8 traversal of 64 rays by one wave with work sharing between the lanes.
+//
+// Measured on the bench workload (profiles/r01_experiments.md #17, #25): the traversal kernel is VALU-issue bound and
+// its node steps run with 47 % of the lanes busy, because a wave lasts as long as its longest walk while the other
+// lanes sit idle.  Handing whole rays to other waves does not pay on gfx950 (#13, #21, #28: the walk loses its
+// co-resident neighbours and becomes memory-bound).  Here the idle lanes stay in the wave and take over PART of a
+// busy lane's walk instead: a lane with pending node groups on its stack gives the oldest one (the largest, farthest
+// subtree) to an idle lane, which continues that ray from there.
+//
+// A ray's result lives in LDS (`res`, indexed by the ray's home lane) so that every lane working on the ray prunes
+// against the same bound and publishes improvements to it
+// ballot... (see publish step: one LDS 64-bit atomic minimum on (t, triangle id), then the winner stores its payload).  The result is the same as in traverse_wide.h:
+// closest = smallest t in (tmin, tmax), ties -> smallest triangle id; any = exists (order-independent definitions).
+#pragma once
+#include "traverse_wide.h"
+
+// per-wave LDS block: 64 x (u64 key, slot, u, v)
+#define VKRT_SHARE_LDS_WORDS 320
+struct ShareRes
+{
+  unsigned long long* key;  // closest: float bits of the best t << 32 | triangle id of the best hit (tie rule); initial tmax << 32 | ~0
+  int* slot;                // triangle slot of the best hit, -1 = none
+  float* u;
+  float* v;
+};
+VKRT_DEV ShareRes shareRes(int* lds320)
+{
+  ShareRes r;
+  r.key = (unsigned long long*)lds320; r.slot = lds320 + 128; r.u = (float*)(lds320 + 192); r.v = (float*)(lds320 + 256);
+  return r;
+}
+
+// lane index of the r-th (0-based) set bit of m; r < popcount(m)
+VKRT_DEV int nthSetBit(unsigned long long m, unsigned r)
+{
+  unsigned w = (unsigned)m, base = 0u;
+  unsigned c = (unsigned)__popc(w);
+  if(r >= c) { r -= c; w = (unsigned)(m >> 32); base = 32u; }
+  c = (unsigned)__popc(w & 0xffffu);
+  if(r >= c) { r -= c; w >>= 16; base += 16u; }
+  c = (unsigned)__popc(w & 0xffu);
+  if(r >= c) { r -= c; w >>= 8; base += 8u; }
+  c = (unsigned)__popc(w & 0xfu);
+  if(r >= c) { r -= c; w >>= 4; base += 4u; }
+  c = (unsigned)__popc(w & 0x3u);
+  if(r >= c) { r -= c; w >>= 2; base += 2u; }
+  if(r >= (w & 1u)) base += 1u;
+  return (int)base;
+}
+
+// Must be called by all 64 lanes of a one-wave workgroup (lanes without a ray pass valid = false and only help).
+// stk: this lane's stack column (stride 64 entries), res: the wave's ShareRes block.
+template <bool COUNT, bool ANYHIT>
+VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, uint2* stk, ShareRes res, RayHit& hit,
+                                   TravCount& tc)
+{
+  const float4* __restrict__ nodes = sc.nodes;
+  const float4* __restrict__ tris = sc.tris;
+  const int stride = 64;
+  const int cap = (int)(sc.stackCap >> 1);
+  const int lane = (int)lane_id();
+  const unsigned shareMin = sc.shareMinIdle;
+  const unsigned long long below = (1ull << lane) - 1ull;
+
+  res.key[lane] = ((unsigned long long)__float_as_uint(tmax) << 32) | 0xffffffffull;
+  res.slot[lane] = -1; res.u[lane] = 0.0f; res.v[lane] = 0.0f;
+
+  int owner = lane;  // home lane of the ray this lane is working on
+  f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  bool px = !(id.x < 0.0f), py = !(id.y < 0.0f), pz = !(id.z < 0.0f);
+  unsigned octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+  uint2 G = make_uint2(0u, (valid && sc.rootRef != VKRT_TRAV_DONE) ? 0x80000000u : 0u);
+  uint2 T = make_uint2(0u, 0u);
+  int sp = 0, sb = 0, nPost = 0;  // node groups live in [sb, sp), parked triangle groups in [cap - nPost, cap)
+  unsigned steps = sc.stepLimit;
+  bool busy = G.y != 0u;
+
+  for(unsigned iter = 0;; iter++)
+  {
+    const unsigned long long busyMask = __ballot(busy);
+    if(busyMask == 0ull)
+      break;
+    // ---- work sharing (every 4th step): idle lanes adopt the oldest pending node group of busy lanes ---------------------
+    if((iter & sc.sharePeriodMask) == sc.sharePeriodMask && (unsigned)__popcll(~busyMask) >= shareMin)
+    {
+      const unsigned long long donorMask = __ballot(busy && sp - sb >= 1), idleMask = ~busyMask;
+      if(donorMask != 0ull)
+      {
+        const unsigned n = min((unsigned)__popcll(donorMask), (unsigned)__popcll(idleMask));
+        const bool gives = busy && sp - sb >= 1 && (unsigned)__popcll(donorMask & below) < n;
+        const unsigned myRank = (unsigned)__popcll(idleMask & below);
+        const bool takes = !busy && myRank < n;
+        uint2 e = make_uint2(0u, 0u);
+        if(gives)
+        {
+          e = stk[sb * stride];
+          sb++;
+        }
+        const int src = takes ? nthSetBit(donorMask, myRank) : lane;
+        const unsigned ex = (unsigned)__shfl((int)e.x, src), ey = (unsigned)__shfl((int)e.y, src);
+        const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
+        const float dx = __shfl(d.x, src), dy = __shfl(d.y, src), dz = __shfl(d.z, src);
+        const float tm = __shfl(tmax, src);
+        const int ow = __shfl(owner, src);
+        if(takes)
+        {
+          o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); tmax = tm;
+          id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+          px = !(id.x < 0.0f); py = !(id.y < 0.0f); pz = !(id.z < 0.0f);
+          octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+          G = make_uint2(ex, ey);
+          T = make_uint2(0u, 0u);
+          sp = 0; sb = 0; nPost = 0;
+          owner = ow;
+          steps = sc.stepLimit;
+          busy = true;
+        }
+      }
+    }
+    // ---- one step of every busy lane's walk (same step as w8run) -----------------------------------------------------
+    bool found = false;  // this lane has a candidate hit to publish
+    float ct = 0.0f, cu = 0.0f, cv = 0.0f;
+    int cslot = -1, cgid = 0;
+    if(busy)
+    {
+      float bt = tmax;
+      int bg = -1;
+      bool finished = false;
+      if(ANYHIT)
+        finished = res.slot[owner] >= 0;  // somebody already found an occluder for this ray
+      else
+      {
+        const unsigned long long k = res.key[owner];
+        bt = __uint_as_float((unsigned)(k >> 32));
+        bg = (int)(unsigned)k;
+      }
+      if(!finished)
+      {
+        auto testOne = [&]() {
+          const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
+          T.y &= T.y - 1u;
+          const unsigned s = T.x + i;
+          const float4 a = tris[s * VKRT_TRI_QUADS + 0];
+          const float4 b = tris[s * VKRT_TRI_QUADS + 1];
+          const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+          if(COUNT)
+          {
+            tc.tris++;
+            if(lane == __ffsll((long long)__ballot(1)) - 1) tc.waveTriSteps++;
+          }
+          float t, u, v;
+          if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v) && t > tmin)
+          {
+            if(ANYHIT)
+            {
+              if(t < tmax && !found)
+              {
+                found = true; ct = t; cslot = (int)s;
+              }
+            }
+            else
+            {
+              const int gid = __float_as_int(c.y);
+              const float rt = found ? ct : bt;
+              const int rg = found ? cgid : bg;
+              if(t < rt || (t == rt && gid < rg))
+              {
+                found = true; ct = t; cu = u; cv = v; cslot = (int)s; cgid = gid;
+              }
+            }
+          }
+        };
+        if(G.y & 0xff000000u)
+        {
+          const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
+          const unsigned slot = (bitIdx - 24u) ^ octinv;
+          const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
+          G.y &= ~(1u << bitIdx);
+          if((G.y & 0xff000000u) && sp + nPost < cap)
+          {
+            stk[sp * stride] = G;
+            sp++;
+          }
+          uint2 Tn;
+          w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bt, G, Tn, tc);
+          if(Tn.y != 0u)
+          {
+            if(T.y != 0u)
+            {
+              if(nPost < VKRT_W8_MAX_POSTPONED && sp + nPost < cap)
+              {
+                nPost++;
+                stk[(cap - nPost) * stride] = T;
+              }
+              else
+              {
+                while(T.y != 0u && !(ANYHIT && found))
+                  testOne();
+                T.y = 0u;
+              }
+            }
+            T = Tn;
+          }
+        }
+        if((G.y & 0xff000000u) == 0u && sp > sb)
+        {
+          sp--;
+          G = stk[sp * stride];
+        }
+        if(T.y == 0u && nPost > 0)
+        {
+          T = stk[(cap - nPost) * stride];
+          nPost--;
+        }
+        if(T.y != 0u && !(ANYHIT && found))
+          testOne();
+        if(ANYHIT && found)
+          finished = true;
+        else if((G.y & 0xff000000u) == 0u && T.y == 0u && nPost == 0)
+          finished = true;  // (sp == sb here: the refill above would have popped otherwise)
+        else if(--steps == 0u)
+          finished = true;
+      }
+      if(finished)
+      {
+        busy = false;
+        G = make_uint2(0u, 0u);
+        T = make_uint2(0u, 0u);
+        sp = 0; sb = 0; nPost = 0;
+      }
+    }
+    // ---- publish improvements: LDS atomic minimum on (t, id), the winner leaves its payload ------------------------------
+    if(found)
+    {
+      if(ANYHIT)
+        res.slot[owner] = cslot;
+      else
+      {
+        const unsigned long long mine = ((unsigned long long)__float_as_uint(ct) << 32) | (unsigned)cgid;
+        atomicMin(&res.key[owner], mine);
+        if(res.key[owner] == mine)
+        {
+          res.slot[owner] = cslot; res.u[owner] = cu; res.v[owner] = cv;
+        }
+      }
+    }
+  }
+  hit.t = __uint_as_float((unsigned)(res.key[lane] >> 32)); hit.u = res.u[lane]; hit.v = res.v[lane]; hit.slot = res.slot[lane];
+  if(ANYHIT)
+    hit.t = tmax;
+}

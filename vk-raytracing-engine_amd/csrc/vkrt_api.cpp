@@ -21,6 +21,7 @@
 #include "kernels.h"
 
 #define VKRT_TRI_THRESHOLD_DEFAULT 1
+#define VKRT_WF_SHARE_DEFAULT 16
 #include "lbvh.h"
 
 namespace {
@@ -307,6 +308,9 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   D.stackCap = 1;
   D.layout = 0;
   D.stepLimit = 64;
+  D.triThreshold = 0;
+  D.shareMinIdle = 0;
+  D.sharePeriodMask = 0;
 
   void* p = nullptr;
   if(hipMalloc(&p, 64) != hipSuccess) return bail(fail(VKRT_ERR_OUT_OF_MEMORY, "hipMalloc(work counter)"));
@@ -417,7 +421,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     {
       s->dev.layout = 1;
       s->dev.rootRef = tris.empty() ? VKRT_TRAV_DONE : 0;
-      s->dev.stackCap = 2 * (w8.maxDepth + 3);
+      s->dev.stackCap = 2 * (w8.maxDepth + 1);  // at most one pending group per level (uint2 entries = 2 words)
       s->info.node_count = w8.nodeCount;
       s->info.max_depth = w8.maxDepth;
       s->info.sah_cost = w8.sahCost;
@@ -487,7 +491,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
       s->dev.triShade = (const uint4*)s->accelShade;
       s->dev.layout = 1;
       s->dev.rootRef = 0;
-      s->dev.stackCap = 2 * (w8.maxDepth + 3);
+      s->dev.stackCap = 2 * (w8.maxDepth + 1);  // at most one pending group per level (uint2 entries = 2 words)
       s->info.node_count = w8.nodeCount;
       s->info.max_depth = w8.maxDepth;
       s->info.sah_cost = w8.sahCost;
@@ -514,6 +518,8 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   }
   s->dev.stepLimit = 4u * (s->info.node_count + s->info.triangle_count) + 64u;
   s->dev.triThreshold = 0;
+  s->dev.shareMinIdle = 0;
+  s->dev.sharePeriodMask = 0;
   if(s->dev.layout == 1)
   {
     // triangle postponing (traverse_wide.h): lanes with pending triangles before a wave tests them; 0 = immediate
@@ -522,6 +528,11 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     s->dev.triThreshold = (uint32_t)(v < 0 ? 0 : (v > 65 ? 65 : v));
     if(s->dev.triThreshold != 0u)
       s->dev.stackCap += 2 * VKRT_W8_MAX_POSTPONED;  // room for parked triangle groups (uint2 entries)
+    // work sharing inside a traversal wave (traverse_share.h): minimum number of idle lanes before they take over subtrees
+    const char* sh = getenv("VKRT_WF_SHARE");
+    const int shv = sh ? atoi(sh) : VKRT_WF_SHARE_DEFAULT;
+    s->dev.shareMinIdle = (uint32_t)(shv < 0 ? 0 : (shv > 64 ? 64 : shv));
+    s->dev.sharePeriodMask = getenv("VKRT_WF_SHARE_PERIOD") ? (uint32_t)atoi(getenv("VKRT_WF_SHARE_PERIOD")) : 0u;
   }
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
   if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)

@@ -33,6 +33,7 @@
 #include "shade.h"
 #include "traverse.h"
 #include "traverse_wide.h"
+#include "traverse_share.h"
 
 #define WF_BLOCK 256
 #define VKRT_WF_SUBFRAMES_DEFAULT 2
@@ -177,6 +178,21 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_init(const TraceParams P, const
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 6, red);
 }
 
+// hit of a finished walk -> H0 (+ H1 for closest hits) of its stream slot
+VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int type, unsigned qi, const RayHit& hit)
+{
+  int inst = hit.slot >= 0 ? 0 : -1;
+  if(type == 0 && hit.slot >= 0)
+  {
+    // first hops of the hit shader's attribute fetch, taken here: the triangle's shading record and its instance id
+    // travel with the hit, so the closest-hit shading starts at the vertex / material loads
+    const uint4 ts = P.sc.triShade[hit.slot];
+    inst = __float_as_int(P.sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
+    plane(B, par, 0, WF_H1)[qi] = make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w));
+  }
+  plane(B, par, type, WF_H0)[qi] = make_float4(hit.t, hit.u, hit.v, __int_as_float(inst));
+}
+
 // ---- traversal: one thread per queued ray, workgroups homogeneous in ray type -----------------------------------
 template <bool COUNT, bool WIDE, int TB>
 __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
@@ -198,21 +214,35 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
   const unsigned count = anyHit ? countS : countC;
   unsigned nRays = 0;
   TravCount tc;
-  if(qi < count)
+  __shared__ int shareLds[VKRT_SHARE_LDS_WORDS];
+  if(WIDE && TB == 64 && P.sc.shareMinIdle != 0u && P.sc.triThreshold != 0u)  // launch-uniform
+  {
+    // the whole wave walks together: lanes past the end of the stream have no ray of their own but help
+    const bool valid = qi < count;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    if(valid)
+    {
+      r0 = plane(B, par, type, WF_R0)[qi];
+      r1 = plane(B, par, type, WF_R1)[qi];
+    }
+    RayHit hit;
+    uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
+    if(anyHit)
+      traverse_wide8_share<COUNT, true>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
+    else
+      traverse_wide8_share<COUNT, false>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
+    if(valid)
+    {
+      storeHit(P, B, par, type, qi, hit);
+      nRays = 1;
+    }
+  }
+  else if(qi < count)
   {
     const float4 r0 = plane(B, par, type, WF_R0)[qi], r1 = plane(B, par, type, WF_R1)[qi];
     RayHit hit;
     traverse_any<COUNT, WIDE>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc);
-    int inst = hit.slot >= 0 ? 0 : -1;
-    if(!anyHit && hit.slot >= 0)
-    {
-      // first hops of the hit shader's attribute fetch, taken here: the triangle's shading record and its instance id
-      // travel with the hit, so k_wf_shade_closest starts at the vertex / material loads
-      const uint4 ts = P.sc.triShade[hit.slot];
-      inst = __float_as_int(P.sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
-      plane(B, par, 0, WF_H1)[qi] = make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w));
-    }
-    plane(B, par, type, WF_H0)[qi] = make_float4(hit.t, hit.u, hit.v, __int_as_float(inst));
+    storeHit(P, B, par, type, qi, hit);
     nRays = 1;
   }
   __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (TB / 64)];
