@@ -3,11 +3,13 @@
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r01"
+no_bench = "--no-bench" in sys.argv
 src = os.path.join(ROOT, "gpurun_out", "final")
 prof = os.path.join(ROOT, "profiles")
-line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith("{")][-1]
-open(os.path.join(prof, f"{tag}_bench.json"), "w").write(line)
+if not no_bench:
+    line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith("{")][-1]
+    open(os.path.join(prof, f"{tag}_bench.json"), "w").write(line)
 
 
 def newest(pattern):

@@ -7,7 +7,6 @@ rm -rf $OUT; mkdir -p $OUT
 step() { local name=$1 secs=$2; shift 2; timeout -k 10 $secs "$@" > $OUT/$name.log 2>&1; local rc=$?; echo "$name rc=$rc" | tee -a $OUT/round.log; [ $rc -ge 124 ] && { echo TIMEOUT | tee -a $OUT/round.log; exit $rc; }; return 0; }
 : > $OUT/round.log
 step pytest 600 python -m pytest tests -m gpu -q
-step bench 600 python bench.py
 export TMPDIR=/tmp
 cd /tmp
 # per-kernel durations that bench.py's roofline must agree with are those of un-overlapped launches: one sub-frame
@@ -20,4 +19,8 @@ unset VKRT_WF_SUBFRAMES
 # the default configuration (two sub-frames on internal streams: kernels overlap, durations are not exclusive)
 step stats_pipelined 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $R/bench.py --no-cpu-baseline
 cd $R
+# the bench line quotes profiles/pmc_traffic.json and pmc_issue.json: derive them from the passes above first (the same
+# collector runs again on the workstation over the merged gpurun_out/), then take the line
+python tools/collect_profiles.py $TAG --no-bench > $OUT/collect.log 2>&1 || echo "collect failed" | tee -a $OUT/round.log
+step bench 600 python bench.py
 tail -3 $OUT/pytest.log; tail -1 $OUT/bench.log | cut -c1-400; cat $OUT/stats/*/*kernel_stats.csv | cut -c1-150 | head -6
