@@ -14,38 +14,21 @@
 #pragma once
 #include "traverse_wide.h"
 
-// per-wave LDS block: 64 x (u64 key, slot, u, v)
-#define VKRT_SHARE_LDS_WORDS 320
+// per-wave LDS block: 64 x (u64 key, slot, u, v, donor lane by rank)
+#define VKRT_SHARE_LDS_WORDS 384
 struct ShareRes
 {
   unsigned long long* key;  // closest: float bits of the best t << 32 | triangle id of the best hit (tie rule); initial tmax << 32 | ~0
   int* slot;                // triangle slot of the best hit, -1 = none
   float* u;
   float* v;
+  int* donor;               // scratch of a sharing step: lane of the r-th donor
 };
 VKRT_DEV ShareRes shareRes(int* lds320)
 {
   ShareRes r;
-  r.key = (unsigned long long*)lds320; r.slot = lds320 + 128; r.u = (float*)(lds320 + 192); r.v = (float*)(lds320 + 256);
+  r.key = (unsigned long long*)lds320; r.slot = lds320 + 128; r.u = (float*)(lds320 + 192); r.v = (float*)(lds320 + 256); r.donor = lds320 + 320;
   return r;
-}
-
-// lane index of the r-th (0-based) set bit of m; r < popcount(m)
-VKRT_DEV int nthSetBit(unsigned long long m, unsigned r)
-{
-  unsigned w = (unsigned)m, base = 0u;
-  unsigned c = (unsigned)__popc(w);
-  if(r >= c) { r -= c; w = (unsigned)(m >> 32); base = 32u; }
-  c = (unsigned)__popc(w & 0xffffu);
-  if(r >= c) { r -= c; w >>= 16; base += 16u; }
-  c = (unsigned)__popc(w & 0xffu);
-  if(r >= c) { r -= c; w >>= 8; base += 8u; }
-  c = (unsigned)__popc(w & 0xfu);
-  if(r >= c) { r -= c; w >>= 4; base += 4u; }
-  c = (unsigned)__popc(w & 0x3u);
-  if(r >= c) { r -= c; w >>= 2; base += 2u; }
-  if(r >= (w & 1u)) base += 1u;
-  return (int)base;
 }
 
 // Must be called by all 64 lanes of a one-wave workgroup (lanes without a ray pass valid = false and only help).
@@ -87,25 +70,26 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
       if(donorMask != 0ull)
       {
         const unsigned n = min((unsigned)__popcll(donorMask), (unsigned)__popcll(idleMask));
-        const bool gives = busy && sp - sb >= 1 && (unsigned)__popcll(donorMask & below) < n;
-        const unsigned myRank = (unsigned)__popcll(idleMask & below);
-        const bool takes = !busy && myRank < n;
+        const unsigned giveRank = (unsigned)__popcll(donorMask & below), takeRank = (unsigned)__popcll(idleMask & below);
+        const bool gives = busy && sp - sb >= 1 && giveRank < n;
+        const bool takes = !busy && takeRank < n;
         uint2 e = make_uint2(0u, 0u);
         if(gives)
         {
           e = stk[sb * stride];
           sb++;
+          res.donor[giveRank] = lane;  // r-th donor feeds the r-th idle lane
         }
-        const int src = takes ? nthSetBit(donorMask, myRank) : lane;
+        const int src = takes ? res.donor[takeRank] : lane;
         const unsigned ex = (unsigned)__shfl((int)e.x, src), ey = (unsigned)__shfl((int)e.y, src);
         const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
         const float dx = __shfl(d.x, src), dy = __shfl(d.y, src), dz = __shfl(d.z, src);
+        const float ix = __shfl(id.x, src), iy = __shfl(id.y, src), iz = __shfl(id.z, src);
         const float tm = __shfl(tmax, src);
         const int ow = __shfl(owner, src);
         if(takes)
         {
-          o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); tmax = tm;
-          id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+          o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); id = mk3(ix, iy, iz); tmax = tm;
           px = !(id.x < 0.0f); py = !(id.y < 0.0f); pz = !(id.z < 0.0f);
           octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
           G = make_uint2(ex, ey);
@@ -187,7 +171,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           {
             if(T.y != 0u)
             {
-              if(nPost < VKRT_W8_MAX_POSTPONED && sp + nPost < cap)
+              if(__builtin_expect(nPost < VKRT_W8_MAX_POSTPONED && sp + nPost < cap, 1))
               {
                 nPost++;
                 stk[(cap - nPost) * stride] = T;
@@ -222,12 +206,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           finished = true;
       }
       if(finished)
-      {
-        busy = false;
-        G = make_uint2(0u, 0u);
-        T = make_uint2(0u, 0u);
-        sp = 0; sb = 0; nPost = 0;
-      }
+        busy = false;  // (G, T and the stack indices are dead until the lane adopts new work)
     }
     // ---- publish improvements: LDS atomic minimum on (t, id), the winner leaves its payload ------------------------------
     if(found)
