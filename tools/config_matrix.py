@@ -1,0 +1,177 @@
+"""Every BASELINE.json config on one MI355X box: rate, frame time and parity against the CPU oracle.
+
+    python tools/config_matrix.py [--out gpurun_out/configs.json] [--cpu-rows 24]
+
+  C1  cornell 256x256, 1 spp, depth 1                  CPU oracle only (the ground-truth config), timed
+  C2  cornell 1280x720, depth 4, 64 spp                 (a) 64 progressive frames x 1 spp (the reference's way), (b) one launch x 64 spp;
+                                                        GPU LBVH build + wavefront pipeline; RMSE vs oracle on evenly spaced rows
+  C3  Sponza-class atrium 1920x1080, 16 spp, depth 8    = bench.py's workload; here: rate + RMSE on sampled rows of frame 0 and 1
+  C4  atrium 3840x2160, 16 spp, depth 8, 8 shards       this GPU renders shard 0 of 8 (its 1/8 of the rows): per-GPU rate + parity of its rows
+  C5  hybrid mode (suntemple stand-in: the atrium)      ray-cast G-buffer + shadows + AO + GI + post, 1920x1080: ms per frame + parity
+
+The cornell scene is the reference asset flattened (tests/golden/cornell_flat.npz); Sponza / suntemple are git-ignored
+upstream, the seeded atrium stands in.  RMSE is over pixels and RGB of the linear rgba32f image, same seed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import torch
+
+import vkrt_amd  # noqa: F401
+from vkrt_amd import abi
+from vkrt_amd.flat_scene import FlatScene, make_push_constants, uniforms_from_matrices
+from vkrt_amd.renderer import Renderer
+from vkrt_amd.sharding import make_shard, shard_row_indices
+import atrium
+import camera_np
+import oracle_py
+
+
+def cam_for(w, h, **kw):
+    return uniforms_from_matrices(*camera_np.global_uniforms(width=w, height=h, **kw))
+
+
+def parity(gpu_rows, ref_rows):
+    """RMSE over pixels and RGB (pixels that are NaN on both sides -- pow of a negative value in post.frag -- are skipped and
+    counted), fraction of pixels whose bit patterns differ, largest absolute difference."""
+    a, b = gpu_rows[..., :3].astype(np.float64), ref_rows[..., :3].astype(np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.where(both_nan, 0.0, a - b)
+    return {"rmse": float(np.sqrt(np.mean(d * d))), "max_abs": float(np.abs(d).max()),
+            "pixels_differing": float(np.mean(np.any(gpu_rows.view(np.uint32) != ref_rows.view(np.uint32), axis=-1))),
+            "nan_on_both_sides": int(both_nan.any(axis=-1).sum()), "rows_compared": int(gpu_rows.shape[0])}
+
+
+def timed_frames(r, frames, W, H, cam, spp, depth, lights, shard=None, image=None, seed0=0, frame0=0):
+    """Runs `frames` progressive frames; returns (image tensor, ms per frame, rays per frame)."""
+    torch.cuda.synchronize()
+    r.reset_counters()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        pc = make_push_constants(samples=spp, depth=depth, frame=frame0 + f, lights_count=lights)
+        image = r.pathtrace(pc, cam, W, H, seed=seed0 + f, shard=shard, image=image)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / frames
+    c = r.counters()
+    return image, ms, (c["rays_closest"] + c["rays_shadow"]) / frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "configs.json"))
+    ap.add_argument("--cpu-rows", type=int, default=24, help="rows of each image the oracle renders for the parity figure")
+    a = ap.parse_args()
+    threads = min(16, os.cpu_count() or 1)
+    out = {"device": torch.cuda.get_device_name(0), "cpu_threads": threads, "configs": {}}
+    cornell = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_flat.npz"))
+    orc_c = oracle_py.OracleScene(cornell)
+
+    # ---- C1: CPU only
+    W = H = 256
+    cam = cam_for(W, H)
+    pc = make_push_constants(samples=1, depth=1, frame=0, lights_count=1)
+    t0 = time.perf_counter()
+    img, c = orc_c.render(pc, cam, W, H, seed=0, threads=1)
+    dt = time.perf_counter() - t0
+    rays = c["rays_closest"] + c["rays_shadow"]
+    out["configs"]["C1_cornell_256_1spp_d1_cpu"] = {"rays": rays, "seconds_1_thread": dt, "Mrays_s_1_thread": rays / dt / 1e6,
+                                                    "mean_radiance": float(img[..., :3].mean())}
+    print("C1", out["configs"]["C1_cornell_256_1spp_d1_cpu"], flush=True)
+
+    # ---- C2: cornell 720p, depth 4, 64 spp, LBVH build on the GPU
+    W, H = 1280, 720
+    cam = cam_for(W, H)
+    r = Renderer(cornell, device=0, build="lbvh")
+    rows = np.unique(np.linspace(0, H - 1, a.cpu_rows).astype(np.uint32))
+    res = {"build": r.accel_info() if hasattr(r, "accel_info") else None}
+    # (a) 64 frames x 1 spp, seed = frame index
+    timed_frames(r, 4, W, H, cam, 1, 4, 1)  # warm-up
+    img, ms, rpf = timed_frames(r, 64, W, H, cam, 1, 4, 1)
+    ref = np.zeros((len(rows), W, 4), np.float32)
+    for f in range(64):
+        orc_c.render(make_push_constants(samples=1, depth=4, frame=f, lights_count=1), cam, W, H, seed=f, rows=rows, image=ref, threads=threads)
+    res["progressive_64x1spp"] = {"ms_per_frame": ms, "ms_total": ms * 64, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref)}
+    # (b) one launch x 64 spp
+    timed_frames(r, 1, W, H, cam, 64, 4, 1)
+    img, ms, rpf = timed_frames(r, 3, W, H, cam, 64, 4, 1, seed0=7)
+    img, _, _ = timed_frames(r, 1, W, H, cam, 64, 4, 1, seed0=7)
+    ref, _ = orc_c.render(make_push_constants(samples=64, depth=4, frame=0, lights_count=1), cam, W, H, seed=7, rows=rows, threads=threads)
+    res["single_launch_64spp"] = {"ms_per_frame": ms, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref)}
+    out["configs"]["C2_cornell_720p_64spp_d4_lbvh"] = res
+    print("C2", res, flush=True)
+    r.close()
+
+    # ---- C3 / C4 / C5: atrium
+    flat, info = atrium.build_atrium(262144, seed=1)
+    orc_a = oracle_py.OracleScene(flat, build_bvh=True, max_leaf=4)
+    lights = len(flat.lights)
+    r = Renderer(flat, device=0, build="sah")
+    W, H = 1920, 1080
+    cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
+    rows = np.unique(np.linspace(0, H - 1, a.cpu_rows).astype(np.uint32))
+    timed_frames(r, 1, W, H, cam, 16, 8, lights)
+    _, ms, rpf = timed_frames(r, 3, W, H, cam, 16, 8, lights)
+    img, _, _ = timed_frames(r, 2, W, H, cam, 16, 8, lights)  # frames 0 and 1 accumulated
+    ref = np.zeros((len(rows), W, 4), np.float32)
+    for f in range(2):
+        orc_a.render(make_push_constants(samples=16, depth=8, frame=f, lights_count=lights), cam, W, H, seed=f, rows=rows, image=ref, threads=threads)
+    out["configs"]["C3_atrium_1080p_16spp_d8"] = {"triangles": int(info["triangles"]) if isinstance(info, dict) and "triangles" in info else None,
+                                                  "ms_per_frame": ms, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref)}
+    print("C3", out["configs"]["C3_atrium_1080p_16spp_d8"], flush=True)
+
+    W, H = 3840, 2160
+    cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
+    shard = make_shard(W, H, 8, 0)
+    timed_frames(r, 1, W, H, cam, 16, 8, lights, shard=shard)
+    _, ms, rpf = timed_frames(r, 3, W, H, cam, 16, 8, lights, shard=shard)
+    img, _, _ = timed_frames(r, 1, W, H, cam, 16, 8, lights, shard=shard)
+    grow = shard_row_indices(H, 8, 0)
+    pick = np.unique(np.linspace(0, len(grow) - 1, a.cpu_rows).astype(np.int64))
+    ref, _ = orc_a.render(make_push_constants(samples=16, depth=8, frame=0, lights_count=lights), cam, W, H, seed=0,
+                          rows=grow[pick].astype(np.uint32), threads=threads)
+    out["configs"]["C4_atrium_4k_16spp_d8_shard0of8"] = {"local_rows": int(len(grow)), "ms_per_frame": ms, "Mrays_s_this_gpu": rpf / ms / 1e3,
+                                                         "note": "one of eight shards; the N-GPU run is bench.py --gpus N (driver)",
+                                                         **parity(img.cpu().numpy()[pick], ref)}
+    print("C4", out["configs"]["C4_atrium_4k_16spp_d8_shard0of8"], flush=True)
+
+    W, H = 1920, 1080
+    cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
+    pc = make_push_constants(samples=1, depth=8, frame=0, lights_count=lights)
+    pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+
+    def hybrid_frame():
+        g = r.gbuffer_raycast(cam, W, H, lights_count=lights)
+        acc = r.hybrid_trace(pc, cam, W, H, g, seed=3)
+        return g, acc, r.post(g["color"], acc, rt_mode=0, use_gi=1)
+
+    hybrid_frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g, acc, disp = hybrid_frame()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / 5
+    rows = np.unique(np.linspace(0, H - 1, a.cpu_rows).astype(np.uint32))
+    go = orc_a.gbuffer(cam, W, H, lights_count=lights, rows=rows, threads=threads)
+    ao, _ = orc_a.hybrid(pc, cam, W, H, go, seed=3, rows=rows, threads=threads)
+    want = oracle_py.post(go["color"], ao, rt_mode=0, use_gi=1)
+    out["configs"]["C5_hybrid_atrium_1080p_shadow_ao_gi"] = {"ms_per_frame": ms, "fps": 1e3 / ms,
+                                                             "gbuffer_color": parity(g["color"].cpu().numpy()[rows], go["color"]),
+                                                             "accumulated": parity(acc.cpu().numpy()[rows], ao),
+                                                             "display": parity(disp.cpu().numpy()[rows], want),
+                                                             "display_note": "post.frag's pow() is outside the bit-exact arithmetic profile: GPU and CPU pow differ in the last bits"}
+    print("C5", out["configs"]["C5_hybrid_atrium_1080p_shadow_ao_gi"], flush=True)
+    r.close()
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(out, open(a.out, "w"), indent=1)
+    print("wrote", a.out)
+
+
+if __name__ == "__main__":
+    main()
