@@ -184,6 +184,12 @@ int vkrt_accel_get_info(const vkrt_scene* scene, vkrt_accel_info* out);
 /* ---- path trace (replaces HelloVulkan::pathtrace :1423-1448 = one
  *      vkCmdTraceRaysKHR over raytrace.rgen/.rchit/.rmiss/raytraceShadow.rmiss) ---- */
 uint32_t vkrt_shard_rows(const vkrt_shard* shard); /* rows of the shard's buffer */
+/* Asynchronous like the command-buffer recording it replaces: returns after enqueueing.  All work is ordered after what
+ * was enqueued on `hip_stream` before the call and complete before anything enqueued on it afterwards (the library may
+ * run parts of a frame on internal streams that fork from and join `hip_stream` through events; no host
+ * synchronisation happens inside the call).  pc->frame > 0 blends into the image the caller kept from the previous
+ * frame (raytrace.rgen:136-145), so the image buffer is caller-owned and persistent.  Calls on one scene handle must
+ * be serialised by the caller. */
 int vkrt_pathtrace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam,
                    const vkrt_trace_opts* opts, const vkrt_shard* shard,
                    float* rgba32f_device, void* hip_stream);
