@@ -32,22 +32,55 @@ def max_shard_rows(height, world_size, strip_rows=STRIP_ROWS):
     return max(len(shard_row_indices(height, world_size, r, strip_rows)) for r in range(world_size))
 
 
+class ImageGatherer:
+    """Per-frame gather of the rank-local strip buffers into the full image, with everything that does not change from
+    frame to frame prepared once: the padded send buffer, the receive buffer, the full image and the row permutation
+    live on the device, so a frame costs one copy, one all_gather and one indexed copy, all enqueued asynchronously
+    (no host synchronisation, no per-frame allocation or host-to-device index upload)."""
+
+    def __init__(self, height, width, world_size, rank, device, dtype=None, strip_rows=STRIP_ROWS, group=None):
+        import torch
+
+        self.world, self.rank, self.group = world_size, rank, group
+        dtype = dtype or torch.float32
+        self.cap = max_shard_rows(height, world_size, strip_rows)
+        self.rows_local = len(shard_row_indices(height, world_size, rank, strip_rows))
+        self.padded = torch.zeros((self.cap, width, 4), dtype=dtype, device=device)
+        self.recv = torch.empty((world_size, self.cap, width, 4), dtype=dtype, device=device)
+        self.full = torch.empty((height, width, 4), dtype=dtype, device=device)
+        src, dst = [], []
+        for r in range(world_size):
+            g = shard_row_indices(height, world_size, r, strip_rows)
+            src.append(r * self.cap + np.arange(len(g), dtype=np.int64))
+            dst.append(g)
+        self.src = torch.from_numpy(np.concatenate(src)).to(device)
+        self.dst = torch.from_numpy(np.concatenate(dst)).to(device)
+
+    def gather(self, local):
+        import torch.distributed as dist
+
+        self.padded[: self.rows_local].copy_(local, non_blocking=True)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(self.recv, self.padded, group=self.group)
+        else:
+            parts = list(self.recv.unbind(0))
+            dist.all_gather(parts, self.padded, group=self.group)
+        flat = self.recv.view(self.world * self.cap, *self.recv.shape[2:])
+        self.full.index_copy_(0, self.dst, flat.index_select(0, self.src))
+        return self.full
+
+
+_gatherers = {}
+
+
 def gather_image(local, height, world_size, rank, strip_rows=STRIP_ROWS, group=None):
     """all_gather the per-rank strip buffers and un-interleave into the full [H, W, 4] image.
-    `local` is a torch tensor [rows_r, W, 4] on any device; every rank returns the full image."""
-    import torch
-    import torch.distributed as dist
-
+    `local` is a torch tensor [rows_r, W, 4] on any device; every rank returns the full image (a buffer that the next
+    call with the same geometry overwrites)."""
     if world_size <= 1:
         return local
-    W = local.shape[1]
-    cap = max_shard_rows(height, world_size, strip_rows)
-    padded = torch.zeros((cap, W, 4), dtype=local.dtype, device=local.device)
-    padded[: local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world_size)]
-    dist.all_gather(parts, padded, group=group)
-    full = torch.empty((height, W, 4), dtype=local.dtype, device=local.device)
-    for r in range(world_size):
-        idx = torch.from_numpy(shard_row_indices(height, world_size, r, strip_rows)).to(local.device)
-        full[idx] = parts[r][: idx.shape[0]]
-    return full
+    key = (height, local.shape[1], world_size, rank, str(local.device), local.dtype, strip_rows, id(group))
+    g = _gatherers.get(key)
+    if g is None:
+        g = _gatherers[key] = ImageGatherer(height, local.shape[1], world_size, rank, local.device, local.dtype, strip_rows, group)
+    return g.gather(local)
