@@ -323,13 +323,14 @@ void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t
 //   C(n,i) = min( D(n,i), C(n,i-1) )                     (i > 1)
 // and the tree is then rebuilt from the arg-mins.  A greedy largest-area-first widening filled only ~3.5 of
 // the 8 slots on average (many tiny bottom nodes); the DP fills them and merges 1-triangle binary leaves into
-// <=3-triangle leaf children.  c_node : c_prim = 1 : 0.3 reflects ~230 vs ~60 VALU instructions on gfx950.
+// <=3-triangle leaf children.  c_node : c_prim = 1 : 1: a triangle step issues ~70 instructions against ~250 of a node
+// step, but runs with ~21 % of the lanes busy against ~68 % (r01_experiments.md #38), so per useful lane they cost the same.
 // =========================================================================================================
 namespace vkrt {
 namespace {
 
 constexpr float kNodeCost = 1.0f;
-constexpr float kPrimCost = 0.3f;
+constexpr float kPrimCost = 1.0f;
 
 struct W8Child
 {
