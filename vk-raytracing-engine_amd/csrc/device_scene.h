@@ -27,7 +27,6 @@ static_assert(sizeof(DevInstance) == 96, "DevInstance");
 //   material: 128 bytes = GltfPBRMaterial (52 B) padded to four aligned float4 + the descriptors of its four
 //             textures (base colour, metallic-roughness, normal, emissive), so a hit reaches its texels in
 //             one hop from the material record instead of two (no separate descriptor-table lookup)
-//   primInfo: 16 bytes  = PrimMeshInfo (12 B) + pad
 struct DevTexRef
 {
   uint32_t offset;  // first texel in the RGBA8 pool (0 when invalid)
@@ -46,12 +45,6 @@ struct DevMaterial
   DevTexRef tex[4];
 };
 static_assert(sizeof(DevMaterial) == 128, "DevMaterial");
-struct DevPrimInfo
-{
-  PrimMeshInfo p;
-  uint32_t pad;
-};
-static_assert(sizeof(DevPrimInfo) == 16, "DevPrimInfo");
 
 struct DevTexture
 {
@@ -75,12 +68,9 @@ struct DevTexture
 struct DevScene
 {
   const float* positions;     // vec3[]
-  const float* normals;       // vec3[]
   const float* tangents;      // vec4[]
-  const float* texcoords;     // vec2[]
   const uint32_t* indices;
   const float4* vertexPN;     // 2 float4 per vertex (see above)
-  const DevPrimInfo* primInfo;
   const DevMaterial* materials;
   const GltfLight* lights;
   const DevInstance* instances;

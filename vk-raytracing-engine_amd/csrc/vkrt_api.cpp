@@ -219,15 +219,10 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
 
   DevScene& D = s->dev;
   if((rc = upload(s, d->positions, 3 * (size_t)d->vertex_count, &D.positions)) != VKRT_OK) return bail(rc);
-  if((rc = upload(s, d->normals, 3 * (size_t)d->vertex_count, &D.normals)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, d->tangents, 4 * (size_t)d->vertex_count, &D.tangents)) != VKRT_OK) return bail(rc);
-  if((rc = upload(s, d->texcoords0, 2 * (size_t)d->vertex_count, &D.texcoords)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, d->indices, (size_t)d->index_count, &D.indices)) != VKRT_OK) return bail(rc);
-  // ePrimLookup buffer (hello_vulkan.cpp:363-368)
-  std::vector<DevPrimInfo> lookup(d->prim_mesh_count);
-  for(uint32_t i = 0; i < d->prim_mesh_count; i++)
-    lookup[i] = DevPrimInfo{PrimMeshInfo{d->prim_meshes[i].firstIndex, d->prim_meshes[i].vertexOffset, d->prim_meshes[i].materialIndex}, 0u};
-  if((rc = upload(s, lookup.data(), lookup.size(), &D.primInfo)) != VKRT_OK) return bail(rc);
+  // (normals / uv travel inside vertexPN; the ePrimLookup indirection of hello_vulkan.cpp:363-368 is resolved per triangle
+  // at build time into triShade, so neither is uploaded in its raw form)
   // interleaved (position, normal, uv) records for the closest-hit attribute fetch (rchit:41-66)
   {
     std::vector<float> pn((size_t)d->vertex_count * 8);
