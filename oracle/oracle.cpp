@@ -322,16 +322,19 @@ inline float safe_inv(float d)
   float dd = (fabsf(d) < tiny) ? copysignf(tiny, d) : d;
   return 1.0f / dd;
 }
-// Conservative slab test (far side padded, Ize 2013): true if [tnear,tfar] overlaps [tmin,tmax].
+// Conservative slab test: true if [tnear,tfar] overlaps [tmin,tmax].  Slabs widened by 1e-6 * max(|t0|,|t1|) per axis and the
+// far side by a relative 2e-6 -- the margin covers the rounding of the slab arithmetic (Ize 2013) AND of the triangle test,
+// which can accept a ray just outside the exact triangle; with these margins BVH and brute force agree (see test_oracle.py).
 inline bool isect_box(const RayInv& r, const Aabb& b, float tmin, float tmax, float& tnear)
 {
   float t0x = (b.lo[0] - r.o.x) * r.id.x, t1x = (b.hi[0] - r.o.x) * r.id.x;
   float t0y = (b.lo[1] - r.o.y) * r.id.y, t1y = (b.hi[1] - r.o.y) * r.id.y;
   float t0z = (b.lo[2] - r.o.z) * r.id.z, t1z = (b.hi[2] - r.o.z) * r.id.z;
-  float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-  float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  float px = 1.0e-6f * fmaxf(fabsf(t0x), fabsf(t1x)), py = 1.0e-6f * fmaxf(fabsf(t0y), fabsf(t1y)), pz = 1.0e-6f * fmaxf(fabsf(t0z), fabsf(t1z));
+  float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin));
+  float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax));
   tnear = tn;
-  return tn <= tf * 1.0000004f;
+  return tn <= tf * 1.000002f;
 }
 
 struct Hit

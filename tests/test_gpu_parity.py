@@ -428,3 +428,41 @@ def test_coincident_geometry_tie_rule(kind):
         img = r.pathtrace(pc, cam, W, H, seed=f, image=img)
     assert np.array_equal(img.cpu().numpy().view(np.uint32), img_ref.view(np.uint32))
     r.close()
+
+
+def test_scheduling_variants_and_repeats_are_bit_identical():
+    """Scheduling never changes pixels: sub-frame count, wave-level work sharing, traversal workgroup size and the BVH2 layout
+    must all give the image of the default configuration, and repeating a launch must reproduce it (the pipeline uses
+    atomics for slot claims and for publishing hits; neither may leak into the result).  Variants run in child processes
+    because the switches are read once per process."""
+    import hashlib, os, subprocess, sys, tempfile, textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, hashlib, numpy as np
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); sys.path.insert(0, {os.path.join(root, 'oracle')!r})
+        sys.path.insert(0, {os.path.join(root, 'tools')!r})
+        import vkrt_amd, atrium, camera_np
+        from vkrt_amd.flat_scene import make_push_constants, uniforms_from_matrices
+        from vkrt_amd.renderer import Renderer
+        flat, _ = atrium.build_atrium(20000, seed=3)
+        W, H = 384, 216
+        cam = uniforms_from_matrices(*camera_np.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA))
+        r = Renderer(flat, device=0, build="sah")
+        hs = []
+        for rep in range(2):
+            img = None
+            for f in range(2):
+                img = r.pathtrace(make_push_constants(samples=2, depth=6, frame=f, lights_count=len(flat.lights)), cam, W, H, seed=40 + f, image=img)
+            hs.append(hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest())
+        assert hs[0] == hs[1], "repeat differs"
+        print("HASH", hs[0])
+    """)
+    variants = [{}, {"VKRT_WF_SUBFRAMES": "1"}, {"VKRT_WF_SUBFRAMES": "3"}, {"VKRT_WF_SHARE": "0"}, {"VKRT_WF_SHARE": "4"},
+                {"VKRT_WF_TRAV_BLOCK": "256"}, {"VKRT_TRI_THRESHOLD": "0", "VKRT_WF_SHARE": "0"}, {"VKRT_BVH": "bvh2"}]
+    hashes = []
+    for v in variants:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **v), timeout=300)
+        assert p.returncode == 0, (v, p.stderr[-2000:])
+        hashes.append([l.split()[1] for l in p.stdout.splitlines() if l.startswith("HASH")][0])
+    assert len(set(hashes)) == 1, dict(zip(map(str, variants), hashes))

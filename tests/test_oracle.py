@@ -179,3 +179,32 @@ def test_full_sweep_sah_tree_is_valid(cornell_oracle):
     assert info["max_depth"] < 64
     v, ids = cornell_oracle.triangles()
     assert len(v) == 16732 and np.array_equal(ids[:, 0], np.arange(16732))
+
+
+def test_bruteforce_equals_bvh_on_flat_axis_aligned_geometry():
+    """Regression for the slab-test margins: the atrium is full of axis-aligned, zero-thickness boxes (floor and wall quads).
+    With only the far side padded by 2 ulp (Ize 2013) one pixel in ~1e5 differed between the BVH and the brute-force walk --
+    the triangle test accepts rays that graze an edge from just outside the box.  Rows chosen to include the pixel that
+    exposed it (row 119 of the 384x216 view, frames 0 and 1)."""
+    import os, sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import atrium
+    import camera_np
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants, uniforms_from_matrices
+
+    flat, _ = atrium.build_atrium(20000, seed=3)
+    orc = oracle_py.OracleScene(flat)
+    W, H = 384, 216
+    cam = uniforms_from_matrices(*camera_np.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA))
+    rows = np.array([40, 118, 119, 120, 200], np.uint32)
+    a = np.zeros((len(rows), W, 4), np.float32)
+    b = np.zeros((len(rows), W, 4), np.float32)
+    for f in range(2):
+        pc = make_push_constants(samples=2, depth=6, frame=f, lights_count=len(flat.lights))
+        orc.render(pc, cam, W, H, seed=40 + f, rows=rows, image=a)
+        orc.render(pc, cam, W, H, seed=40 + f, rows=rows, image=b, use_bvh=False)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

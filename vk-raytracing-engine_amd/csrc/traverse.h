@@ -22,17 +22,22 @@ VKRT_DEV float safe_inv(float d)
   return 1.0f / dd;
 }
 
-// conservative slab test against one child box; returns hit and entry distance
+// conservative slab test against one child box; returns hit and entry distance.  The slabs are widened by
+// 1e-6 * max(|t0|, |t1|) per axis and the far side by a relative 2e-6 (the same margins as the wide8 test,
+// traverse_wide.h): the margin has to cover not only the rounding of the slab arithmetic (Ize 2013) but also the rounding of
+// the triangle test, which can accept a ray that passes just outside the exact triangle (a flat, axis-aligned triangle has a
+// zero-thickness box); with the far-side factor alone one pixel in ~1e5 differed between trees (r01_experiments.md #42).
 VKRT_DEV bool box_test(f3 o, f3 id, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float tmax,
                        float& tnear)
 {
   float t0x = (lox - o.x) * id.x, t1x = (hix - o.x) * id.x;
   float t0y = (loy - o.y) * id.y, t1y = (hiy - o.y) * id.y;
   float t0z = (loz - o.z) * id.z, t1z = (hiz - o.z) * id.z;
-  float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-  float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  float px = 1.0e-6f * fmaxf(fabsf(t0x), fabsf(t1x)), py = 1.0e-6f * fmaxf(fabsf(t0y), fabsf(t1y)), pz = 1.0e-6f * fmaxf(fabsf(t0z), fabsf(t1z));
+  float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin));
+  float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax));
   tnear = tn;
-  return tn <= tf * 1.0000004f;
+  return tn <= tf * 1.000002f;
 }
 
 // Moeller-Trumbore on (v0,e1,e2); one IEEE division, only for rays inside the triangle.
