@@ -431,8 +431,8 @@ def test_coincident_geometry_tie_rule(kind):
 
 
 def test_scheduling_variants_and_repeats_are_bit_identical():
-    """Scheduling never changes pixels: sub-frame count, wave-level work sharing, traversal workgroup size and the BVH2 layout
-    must all give the image of the default configuration, and repeating a launch must reproduce it (the pipeline uses
+    """Scheduling never changes pixels: sub-frame count, wave-level work sharing, traversal workgroup size, the BVH2 layout and the
+    megakernel must all give the image of the default configuration, and repeating a launch must reproduce it (the pipeline uses
     atomics for slot claims and for publishing hits; neither may leak into the result).  Variants run in child processes
     because the switches are read once per process."""
     import hashlib, os, subprocess, sys, tempfile, textwrap
@@ -459,7 +459,7 @@ def test_scheduling_variants_and_repeats_are_bit_identical():
         print("HASH", hs[0])
     """)
     variants = [{}, {"VKRT_WF_SUBFRAMES": "1"}, {"VKRT_WF_SUBFRAMES": "3"}, {"VKRT_WF_SHARE": "0"}, {"VKRT_WF_SHARE": "4"},
-                {"VKRT_WF_TRAV_BLOCK": "256"}, {"VKRT_TRI_THRESHOLD": "0", "VKRT_WF_SHARE": "0"}, {"VKRT_BVH": "bvh2"}]
+                {"VKRT_WF_TRAV_BLOCK": "256"}, {"VKRT_TRI_THRESHOLD": "0", "VKRT_WF_SHARE": "0"}, {"VKRT_BVH": "bvh2"}, {"VKRT_MODE": "mega"}]
     hashes = []
     for v in variants:
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **v), timeout=300)
