@@ -322,19 +322,19 @@ inline float safe_inv(float d)
   float dd = (fabsf(d) < tiny) ? copysignf(tiny, d) : d;
   return 1.0f / dd;
 }
-// Conservative slab test: true if [tnear,tfar] overlaps [tmin,tmax].  Slabs widened by 1e-6 * max(|t0|,|t1|) per axis and the
-// far side by a relative 2e-6 -- the margin covers the rounding of the slab arithmetic (Ize 2013) AND of the triangle test,
+// Conservative slab test: true if [tnear,tfar] overlaps [tmin,tmax].  Slabs widened by 2e-5 * max(|t0|,|t1|) per axis and the
+// far side by a relative 4e-5 -- the margin covers the rounding of the slab arithmetic (Ize 2013) AND of the triangle test,
 // which can accept a ray just outside the exact triangle; with these margins BVH and brute force agree (see test_oracle.py).
 inline bool isect_box(const RayInv& r, const Aabb& b, float tmin, float tmax, float& tnear)
 {
   float t0x = (b.lo[0] - r.o.x) * r.id.x, t1x = (b.hi[0] - r.o.x) * r.id.x;
   float t0y = (b.lo[1] - r.o.y) * r.id.y, t1y = (b.hi[1] - r.o.y) * r.id.y;
   float t0z = (b.lo[2] - r.o.z) * r.id.z, t1z = (b.hi[2] - r.o.z) * r.id.z;
-  float px = 1.0e-6f * fmaxf(fabsf(t0x), fabsf(t1x)), py = 1.0e-6f * fmaxf(fabsf(t0y), fabsf(t1y)), pz = 1.0e-6f * fmaxf(fabsf(t0z), fabsf(t1z));
+  float px = 2.0e-5f * fmaxf(fabsf(t0x), fabsf(t1x)), py = 2.0e-5f * fmaxf(fabsf(t0y), fabsf(t1y)), pz = 2.0e-5f * fmaxf(fabsf(t0z), fabsf(t1z));
   float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin));
   float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax));
   tnear = tn;
-  return tn <= tf * 1.000002f;
+  return tn <= tf * 1.00004f;
 }
 
 struct Hit
@@ -947,6 +947,8 @@ void rayGen(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms&
       Hit h = useBvh ? closest_bvh(s, prd.rayOrigin, rd, tMin, tMax, c) : closest_brute(s, prd.rayOrigin, rd, tMin, tMax, c);
       if(log)
       {
+        float ray[8] = {-2.0f, prd.rayOrigin.x, prd.rayOrigin.y, prd.rayOrigin.z, rd.x, rd.y, rd.z, tMax};
+        log->out->insert(log->out->end(), ray, ray + 8);
         float rec[8] = {(float)prd.depth, (float)h.tri, h.t, h.u, h.v, 0, 0, 0};
         log->out->insert(log->out->end(), rec, rec + 8);
       }
@@ -961,6 +963,11 @@ void rayGen(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms&
         float smax = prd.lightDist - 0.1f;
         shadowHit = useBvh ? any_bvh(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c)
                            : any_brute(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c);
+        if(log)
+        {
+          float ray[8] = {-3.0f, prd.rayOrigin.x, prd.rayOrigin.y, prd.rayOrigin.z, prd.shadowRayDir.x, prd.shadowRayDir.y, prd.shadowRayDir.z, smax};
+          log->out->insert(log->out->end(), ray, ray + 8);
+        }
       }
       if(!shadowHit)  // rgen:99-102
       {
@@ -1416,8 +1423,8 @@ int orc_render_rows(const orc_scene* s, const PushConstantRay* pc, const GlobalU
   return 0;
 }
 
-/* Per-segment log of one pixel: records of 8 floats, alternating
- * {depth, gid, t, u, v, 0,0,0} and {-1, shadowHit, hitValue.xyz, weight.xyz}. Returns count of floats. */
+/* Per-segment log of one pixel: records of 8 floats: {-2, o.xyz, d.xyz, tmax} closest ray, {depth, gid, t, u, v, 0,0,0} its
+ * hit, {-3, o.xyz, d.xyz, tmax} shadow ray (if traced), {-1, shadowHit, hitValue.xyz, weight.xyz} segment.  Returns count of floats. */
 int orc_pixel_log(const orc_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, uint32_t seed, uint32_t flags,
                   uint32_t full_w, uint32_t full_h, uint32_t x, uint32_t y, int use_bvh, float* rgba_inout, float* log, int log_cap)
 {

@@ -118,7 +118,7 @@ class OracleScene:
 
     def pixel_log(self, pc, cam, width, height, x, y, seed=0, flags=0, use_bvh=True):
         px = np.zeros(4, np.float32)
-        log = np.zeros(16 * 64 * max(1, pc.samples), np.float32)
+        log = np.zeros(32 * 64 * max(1, pc.samples), np.float32)
         n = lib().orc_pixel_log(self._h, C.byref(pc), C.byref(cam), seed, flags, width, height, x, y, 1 if use_bvh else 0,
                                 px.ctypes.data, log.ctypes.data, log.shape[0])
         return px, log[: min(n, log.shape[0])].reshape(-1, 8)

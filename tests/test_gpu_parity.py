@@ -288,9 +288,19 @@ def test_config3_full_size_rows_sample():
     ref, _ = oracle_py.OracleScene(flat).render(pc, cam, W, H, seed=0, rows=rows, threads=min(16, os.cpu_count() or 1))
     r = Renderer(flat, device=0, build="sah")
     img = r.pathtrace(pc, cam, W, H, seed=0).cpu().numpy()[rows]
-    r.close()
     assert rmse(img, ref) < RMSE_TOL
     assert mismatch_fraction(img, ref) < 1e-4
+    # regression (experiment #44): a bounce ray that leaves the wall z = -9 along the wall (1/d.z = -1.7e6) and hits the floor
+    # 2.4e-8 outside the slab of the floor triangle's box; the wide8 pad, then relative to the node origin's distance only,
+    # was zero here and the hit was pruned.  Brute force, the oracle's tree and both GPU layouts must agree.
+    o = np.array([[-3.2355213165283203, 0.03449827432632446, -9.0]], np.float32)
+    d = np.array([[0.5075250864028931, -0.8616370558738708, -5.960464477539062e-07]], np.float32)
+    orc = oracle_py.OracleScene(flat)
+    bt, bu, bv, bg, _ = orc.trace_rays(o, d, 0.001, 10000.0, use_bvh=False)
+    vt, vu, vv, vg, _ = orc.trace_rays(o, d, 0.001, 10000.0, use_bvh=True)
+    gt, gu, gv, gg = r.trace_rays(o, d, 0.001, 10000.0)
+    assert bg[0] >= 0 and bg[0] == vg[0] == gg[0] and bt[0] == vt[0] == gt[0] and abs(float(bt[0]) - 0.04003806) < 1e-6
+    r.close()
 
 
 def test_wavefront_and_megakernel_modes_agree(cornell_flat):

@@ -22,22 +22,27 @@ VKRT_DEV float safe_inv(float d)
   return 1.0f / dd;
 }
 
-// conservative slab test against one child box; returns hit and entry distance.  The slabs are widened by
-// 1e-6 * max(|t0|, |t1|) per axis and the far side by a relative 2e-6 (the same margins as the wide8 test,
-// traverse_wide.h): the margin has to cover not only the rounding of the slab arithmetic (Ize 2013) but also the rounding of
-// the triangle test, which can accept a ray that passes just outside the exact triangle (a flat, axis-aligned triangle has a
-// zero-thickness box); with the far-side factor alone one pixel in ~1e5 differed between trees (r01_experiments.md #42).
+// Margins of the box tests (binary and wide8).  They have to cover the rounding of the slab arithmetic (Ize 2013) AND of the
+// triangle test: Moeller-Trumbore accepts a ray that passes an edge on the outside by up to ~3 eps |o - v0| / cos(incidence),
+// and a flat axis-aligned triangle has a zero-thickness box, so a margin that only covers the slab arithmetic lets a grazing
+// hit depend on the tree.  Measured (r01_experiments.md #42, #44): far side x (1 + 4e-7) only: 1 pixel in 1e5 differs between
+// trees; 1e-6 / 2e-6: 1 in 1e6; with the values below (incidence cosines down to ~0.05 covered) none in 2e6 pixels x 2 frames.
+#define VKRT_BOX_PAD_ABS 2.0e-5f   // slabs widened by this x max(|t0|, |t1|) per axis
+#define VKRT_BOX_PAD_REL 1.00004f  // far side (and the current best t) scaled by this
+#define VKRT_BOX_PAD_NEAR 0.99996f // wide8: near planes scaled by this (a near plane behind the origin is clamped by tmin anyway)
+
+// conservative slab test against one child box; returns hit and entry distance
 VKRT_DEV bool box_test(f3 o, f3 id, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float tmax,
                        float& tnear)
 {
   float t0x = (lox - o.x) * id.x, t1x = (hix - o.x) * id.x;
   float t0y = (loy - o.y) * id.y, t1y = (hiy - o.y) * id.y;
   float t0z = (loz - o.z) * id.z, t1z = (hiz - o.z) * id.z;
-  float px = 1.0e-6f * fmaxf(fabsf(t0x), fabsf(t1x)), py = 1.0e-6f * fmaxf(fabsf(t0y), fabsf(t1y)), pz = 1.0e-6f * fmaxf(fabsf(t0z), fabsf(t1z));
+  float px = VKRT_BOX_PAD_ABS * fmaxf(fabsf(t0x), fabsf(t1x)), py = VKRT_BOX_PAD_ABS * fmaxf(fabsf(t0y), fabsf(t1y)), pz = VKRT_BOX_PAD_ABS * fmaxf(fabsf(t0z), fabsf(t1z));
   float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin));
   float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax));
   tnear = tn;
-  return tn <= tf * 1.000002f;
+  return tn <= tf * VKRT_BOX_PAD_REL;
 }
 
 // Moeller-Trumbore on (v0,e1,e2); one IEEE division, only for rays inside the triangle.

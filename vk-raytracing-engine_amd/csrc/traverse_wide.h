@@ -6,7 +6,7 @@
 // Per node: cell size 2^(e-127) and origin are folded with the ray into adj_scale = 2^e/d and
 // adj_origin = (origin - o)/d, so each child plane costs one v_cvt_f32_ubyteN + one v_fma_f32.  The fused
 // form has an absolute error ~ eps*|adj_origin| per axis; near planes are therefore moved down and far
-// planes up by 1e-6*|adj_origin| (folded into the per-node constants) and the final comparison carries a
+// planes up by VKRT_BOX_PAD_ABS*|adj_origin| (folded into the per-node constants) and the final comparison carries a
 // relative pad, which keeps the box test conservative.  Children are visited front to back by ray octant
 // using the slot order the builder prepared (bit 24 + (slot ^ octinv) of the hit mask).
 #pragma once
@@ -66,13 +66,20 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
   const float asy = __uint_as_float(((ew >> 8) & 0xffu) << 23) * id.y;
   const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
   const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
-  // Conservative pads folded into per-node constants: near planes move down, far planes up by 1e-6*|adj_origin|
-  // (absolute error of the fused form), and the far planes' scale carries the relative pad (1 + 2e-6 for
-  // positive t; a far plane behind the origin only matters when the box is missed anyway).
-  const float nox = fmaf(fabsf(aox), -1.0e-6f, aox), fox = fmaf(fabsf(aox), 1.0e-6f, aox) * 1.000002f;
-  const float noy = fmaf(fabsf(aoy), -1.0e-6f, aoy), foy = fmaf(fabsf(aoy), 1.0e-6f, aoy) * 1.000002f;
-  const float noz = fmaf(fabsf(aoz), -1.0e-6f, aoz), foz = fmaf(fabsf(aoz), 1.0e-6f, aoz) * 1.000002f;
-  const float fsx = asx * 1.000002f, fsy = asy * 1.000002f, fsz = asz * 1.000002f;
+  // Conservative pads folded into per-node constants (margins: traverse.h): near planes move down and far planes up by an
+  // absolute pad, and both carry a relative pad through their scale and offset (far x (1 + 4e-5), near x (1 - 4e-5); a plane
+  // behind the origin only matters when the box is missed anyway).
+  // (the absolute pad scales with the largest |t| a plane of this node can have on the axis, |adj_origin| + 255 |adj_scale|: a pad
+  // relative to |adj_origin| alone vanishes when the node origin shares a coordinate with the ray origin -- a ray leaving a
+  // wall along the wall, 1/d ~ 1e6 -- and then a hit 2e-8 outside the slab was pruned, r01_experiments.md #44)
+  const float padx = VKRT_BOX_PAD_ABS * fmaf(255.0f, fabsf(asx), fabsf(aox));
+  const float pady = VKRT_BOX_PAD_ABS * fmaf(255.0f, fabsf(asy), fabsf(aoy));
+  const float padz = VKRT_BOX_PAD_ABS * fmaf(255.0f, fabsf(asz), fabsf(aoz));
+  const float nox = (aox - padx) * VKRT_BOX_PAD_NEAR, fox = (aox + padx) * VKRT_BOX_PAD_REL;
+  const float noy = (aoy - pady) * VKRT_BOX_PAD_NEAR, foy = (aoy + pady) * VKRT_BOX_PAD_REL;
+  const float noz = (aoz - padz) * VKRT_BOX_PAD_NEAR, foz = (aoz + padz) * VKRT_BOX_PAD_REL;
+  const float fsx = asx * VKRT_BOX_PAD_REL, fsy = asy * VKRT_BOX_PAD_REL, fsz = asz * VKRT_BOX_PAD_REL;
+  const float nsx = asx * VKRT_BOX_PAD_NEAR, nsy = asy * VKRT_BOX_PAD_NEAR, nsz = asz * VKRT_BOX_PAD_NEAR;  // near planes: t * (1 - 4e-5)
   // quantised planes, near/far by ray direction sign
   const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
   const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
@@ -96,11 +103,11 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
 #pragma unroll
     for(int k = 0; k < 4; k++)
     {
-      const float tnx = fmaf(ubyte_f32(nx[w], k), asx, nox), tfx = fmaf(ubyte_f32(fx[w], k), fsx, fox);
-      const float tny = fmaf(ubyte_f32(ny[w], k), asy, noy), tfy = fmaf(ubyte_f32(fy[w], k), fsy, foy);
-      const float tnz = fmaf(ubyte_f32(nz[w], k), asz, noz), tfz = fmaf(ubyte_f32(fz[w], k), fsz, foz);
+      const float tnx = fmaf(ubyte_f32(nx[w], k), nsx, nox), tfx = fmaf(ubyte_f32(fx[w], k), fsx, fox);
+      const float tny = fmaf(ubyte_f32(ny[w], k), nsy, noy), tfy = fmaf(ubyte_f32(fy[w], k), fsy, foy);
+      const float tnz = fmaf(ubyte_f32(nz[w], k), nsz, noz), tfz = fmaf(ubyte_f32(fz[w], k), fsz, foz);
       const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * 1.000002f));
+      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * VKRT_BOX_PAD_REL));
       const unsigned piece = ((bits4 >> (8 * k)) & 0xffu) << ((bitIndex4 >> (8 * k)) & 0xffu);
       hitmask |= (tn <= tf) ? piece : 0u;
     }
