@@ -476,3 +476,85 @@ def test_scheduling_variants_and_repeats_are_bit_identical():
         assert p.returncode == 0, (v, p.stderr[-2000:])
         hashes.append([l.split()[1] for l in p.stdout.splitlines() if l.startswith("HASH")][0])
     assert len(set(hashes)) == 1, dict(zip(map(str, variants), hashes))
+
+
+def _triangle_soup(n=6000, seed=21):
+    """Random triangles over five orders of magnitude in size, some needle-shaped, some degenerate (zero area), some exactly
+    axis-aligned (zero-thickness boxes), in a 20-unit cube: nothing like an architectural scene."""
+    from vkrt_amd.flat_scene import LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, FlatScene
+
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-10, 10, (n, 3))
+    size = 10.0 ** rng.uniform(-4, 1, (n, 1))
+    a = c + rng.normal(size=(n, 3)) * size
+    b = c + rng.normal(size=(n, 3)) * size
+    d = c + rng.normal(size=(n, 3)) * size
+    needle = rng.random(n) < 0.15
+    d[needle] = a[needle] + (b[needle] - a[needle]) * 0.5 + rng.normal(size=(needle.sum(), 3)) * size[needle] * 1e-4
+    flat_axis = rng.random(n) < 0.2
+    ax = rng.integers(0, 3, n)
+    for k in range(3):
+        m = flat_axis & (ax == k)
+        b[m, k] = a[m, k]
+        d[m, k] = a[m, k]
+    degen = rng.random(n) < 0.02
+    d[degen] = b[degen]
+    pos = np.stack([a, b, d], 1).reshape(-1, 3).astype(np.float32)
+    V = pos.shape[0]
+    idx = np.arange(V, dtype=np.uint32)
+    nrm = np.tile(np.array([0, 1, 0], np.float32), (V, 1))
+    tan = np.tile(np.array([1, 0, 0, 1], np.float32), (V, 1))
+    uv = np.zeros((V, 2), np.float32)
+    pm = np.zeros(1, PRIM_DTYPE)
+    pm[0] = (0, V, 0, V, 0)
+    mats = np.zeros(1, MAT_DTYPE)
+    mats[0]["pbrBaseColorFactor"] = [0.8, 0.8, 0.8, 1]
+    mats[0]["pbrBaseColorTexture"] = mats[0]["metallicRoughnessTexture"] = mats[0]["normalTexture"] = mats[0]["emissiveTexture"] = -1
+    mats[0]["roughnessFactor"] = 0.5
+    nodes = np.zeros(1, NODE_DTYPE)
+    nodes[0]["worldMatrix"] = np.eye(4, dtype=np.float32).ravel()
+    lights = np.zeros(1, LIGHT_DTYPE)
+    lights[0] = ((0, 12, 0), (1, 1, 1), 100.0, 0)
+    return FlatScene(pos, nrm, tan, uv, idx, pm, mats, lights, nodes, [])
+
+
+@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+def test_triangle_soup_ray_queries_equal_brute_force(kind):
+    """Closest-hit and any-hit queries on a hostile triangle set: the GPU tree walk and the oracle's tree walk must return
+    exactly what the oracle's brute-force loop over all triangles returns (rays from everywhere, including axis-parallel ones
+    and rays starting on triangles)."""
+    import oracle_py
+    from vkrt_amd.renderer import Renderer
+
+    flat = _triangle_soup()
+    orc = oracle_py.OracleScene(flat)
+    r = Renderer(flat, device=0, build=kind)
+    rng = np.random.default_rng(5)
+    n = 60000
+    o = rng.uniform(-12, 12, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    axis = rng.integers(0, 3, n)
+    par = rng.random(n) < 0.1  # exactly axis-parallel rays
+    d[par] = 0
+    d[par, axis[par]] = np.where(rng.random(par.sum()) < 0.5, 1.0, -1.0)
+    tiny = rng.random(n) < 0.1  # nearly axis-parallel: one component ~1e-7
+    d[tiny, axis[tiny]] = (rng.uniform(-1, 1, tiny.sum()) * 1e-7).astype(np.float32)
+    on = rng.random(n) < 0.2   # origins on triangles
+    tri = rng.integers(0, flat.positions.shape[0] // 3, n)
+    w = rng.dirichlet((1, 1, 1), n).astype(np.float32)
+    P = flat.positions.reshape(-1, 3, 3)[tri]
+    o[on] = (P[on] * w[on][:, :, None]).sum(1)
+    bt, bu, bv, bg, _ = orc.trace_rays(o, d, 0.001, 10000.0, use_bvh=False)
+    vt, vu, vv, vg, _ = orc.trace_rays(o, d, 0.001, 10000.0, use_bvh=True)
+    gt, gu, gv, gg = r.trace_rays(o, d, 0.001, 10000.0)
+    assert (bg >= 0).mean() > 0.3
+    assert np.array_equal(vg, bg) and np.array_equal(vt.view(np.uint32), bt.view(np.uint32))
+    assert np.array_equal(gg, bg), np.nonzero(gg != bg)[0][:10]
+    for a, b in ((gt, bt), (gu, bu), (gv, bv)):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    _, _, _, ba, _ = orc.trace_rays(o, d, 0.001, 7.5, any_hit=True, use_bvh=False)
+    _, _, _, ga = r.trace_rays(o, d, 0.001, 7.5, any_hit=True)
+    assert np.array_equal(ga >= 0, ba >= 0)
+    r.close()
