@@ -5,12 +5,13 @@
 //
 //   k_wf_init          one thread per pixel: rgen prologue (seed, camera ray of sample 0) -> closest-ray stream.
 //   k_wf_traverse      one thread per queued ray, batch-synchronous: the 64 rays of a wave start together, so the
-//                      top tree levels are fetched as coalesced/broadcast loads.  Workgroups are one wave and
+//                      top tree levels are fetched as coalesced/broadcast loads; lanes that finish early take over
+//                      pending subtrees of their neighbours (traverse_share.h).  Workgroups are one wave and
 //                      homogeneous: the first blocks take the closest-hit stream (rgen:64-75), the rest the shadow
 //                      stream (rgen:85-97, any-hit).  Per-lane stacks in LDS.  Software stand-in for traceRayEXT.
-//   k_wf_shade_closest one thread per closest-hit result: rchit / rmiss, then either a shadow-ray request or the
-//                      segment accumulation (rgen:99-120).
-//   k_wf_shade_shadow  one thread per shadow result: accumulation, next segment / sample / pixel store.
+//   k_wf_shade         one launch for both result streams.  Closest-hit workgroups (dispatched first): one thread per
+//                      closest-hit result, rchit / rmiss, then either a shadow-ray request or the segment accumulation
+//                      (rgen:99-120).  Shadow-result workgroups: accumulation, next segment / sample / pixel store.
 //
 // Path records MOVE with their queue position: a round reads the records of its two input streams front to back
 // and every surviving path writes its new record at the position a block-aggregated ballot compaction assigns
