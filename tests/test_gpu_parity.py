@@ -558,3 +558,44 @@ def test_triangle_soup_ray_queries_equal_brute_force(kind):
     _, _, _, ga = r.trace_rays(o, d, 0.001, 7.5, any_hit=True)
     assert np.array_equal(ga >= 0, ba >= 0)
     r.close()
+
+
+def test_non_power_of_two_and_degenerate_textures(atrium_small):
+    """texture() addressing outside the fast path: sizes that are not powers of two (general modulo for REPEAT), 1x1 and
+    one-texel-wide textures (a dangling texture index is refused at scene creation).
+    Whole image, GPU against oracle, bit for bit; the hybrid G-buffer sampler (descriptor-table path) as well."""
+    import copy
+
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat0, info, camkw = atrium_small
+    flat = copy.deepcopy(flat0)
+    shapes = [(100, 60), (1, 1), (3, 5), (257, 1), (1, 33), (96, 96), (50, 7), (640, 360)]
+    for t, (w, h) in zip(flat.textures, shapes):
+        src = t["rgba8"]
+        ys = (np.arange(h) * src.shape[0] // max(h, 1)) % src.shape[0]
+        xs = (np.arange(w) * src.shape[1] // max(w, 1)) % src.shape[1]
+        t["rgba8"] = np.ascontiguousarray(src[ys][:, xs])
+    bad = copy.deepcopy(flat)
+    bad.materials["emissiveTexture"][0] = 99  # the ABI refuses dangling texture indices (the loader maps undecodable images to 1x1 white)
+    with pytest.raises(Exception, match="out of range"):
+        Renderer(bad, device=0, build="sah")
+    W, H = 256, 144
+    cam = default_camera(W, H, **camkw)
+    orc = oracle_py.OracleScene(flat)
+    r = Renderer(flat, device=0, build="sah")
+    ref = np.zeros((H, W, 4), np.float32)
+    img = None
+    for f in range(2):
+        pc = make_push_constants(samples=3, depth=6, frame=f, lights_count=len(flat.lights))
+        _, c = orc.render(pc, cam, W, H, seed=70 + f, image=ref)
+        img = r.pathtrace(pc, cam, W, H, seed=70 + f, image=img)
+    assert c["tex_taps"] > 0
+    assert np.array_equal(img.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    g = r.gbuffer_raycast(cam, W, H, lights_count=len(flat.lights))
+    go = orc.gbuffer(cam, W, H, lights_count=len(flat.lights))
+    for k in go:
+        assert np.array_equal(g[k].cpu().numpy().view(np.uint32), go[k].view(np.uint32)), k
+    r.close()
