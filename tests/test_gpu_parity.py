@@ -599,3 +599,50 @@ def test_non_power_of_two_and_degenerate_textures(atrium_small):
     for k in go:
         assert np.array_equal(g[k].cpu().numpy().view(np.uint32), go[k].view(np.uint32)), k
     r.close()
+
+
+@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+def test_empty_single_triangle_and_ragged_index_scenes(kind):
+    """Edge inputs of the scene contract: no instances at all (every ray misses), one triangle (a leaf root), and a primMesh
+    whose indexCount is not a multiple of three (the trailing indices are ignored, primitiveCount = indexCount / 3,
+    hello_vulkan.cpp:960-969).  GPU image = oracle image, bit for bit."""
+    import oracle_py
+    from vkrt_amd.flat_scene import LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, FlatScene, make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    pos = np.array([[-2, -1, 0], [2, -1, 0], [0, 2, 0], [3, 3, -1], [4, 3, -1]], np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (5, 1))
+    tan = np.tile(np.array([1, 0, 0, 1], np.float32), (5, 1))
+    uv = np.zeros((5, 2), np.float32)
+    mats = np.zeros(1, MAT_DTYPE)
+    mats[0]["pbrBaseColorFactor"] = [0.7, 0.6, 0.5, 1]
+    mats[0]["pbrBaseColorTexture"] = mats[0]["metallicRoughnessTexture"] = mats[0]["normalTexture"] = mats[0]["emissiveTexture"] = -1
+    mats[0]["roughnessFactor"] = 0.6
+    lights = np.zeros(1, LIGHT_DTYPE)
+    lights[0] = ((0.5, 1.0, 4.0), (1, 1, 1), 40.0, 0)
+    node = np.zeros(1, NODE_DTYPE)
+    node[0]["worldMatrix"] = np.eye(4, dtype=np.float32).ravel()
+    W, H = 96, 64
+    cam = default_camera(W, H, eye=(0, 0.5, 6), center=(0, 0.5, 0))
+    cases = {
+        "empty": (np.zeros(0, np.uint32), np.zeros(0, PRIM_DTYPE), np.zeros(0, NODE_DTYPE)),
+        "single": (np.array([0, 1, 2], np.uint32), np.array([(0, 3, 0, 5, 0)], PRIM_DTYPE), node),
+        "ragged": (np.array([0, 1, 2, 3, 4], np.uint32), np.array([(0, 5, 0, 5, 0)], PRIM_DTYPE), node),
+    }
+    for name, (idx, pm, nd) in cases.items():
+        flat = FlatScene(pos, nrm, tan, uv, idx, pm, mats, lights, nd, [])
+        orc = oracle_py.OracleScene(flat)
+        r = Renderer(flat, device=0, build=kind)
+        ref = np.zeros((H, W, 4), np.float32)
+        img = None
+        for f in range(2):
+            pc = make_push_constants(samples=2, depth=3, frame=f, lights_count=1, clear_color=(0.2, 0.4, 0.6, 1.0))
+            _, c = orc.render(pc, cam, W, H, seed=f, image=ref)
+            img = r.pathtrace(pc, cam, W, H, seed=f, image=img)
+        got = img.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), name
+        if name == "empty":
+            assert c["hits"] == 0 and np.all(got[..., 1] == np.float32(0.4) * np.float32(0.8))
+        else:
+            assert c["hits"] > 0 and r.accel_info()["triangle_count"] == 1
+        r.close()
