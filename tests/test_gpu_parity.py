@@ -646,3 +646,17 @@ def test_empty_single_triangle_and_ragged_index_scenes(kind):
         else:
             assert c["hits"] > 0 and r.accel_info()["triangle_count"] == 1
         r.close()
+
+
+def test_ui_maximum_samples_and_depth(renderers, cornell_oracle):
+    """The largest values the reference's UI allows (samples 1-100, depth 1-30, main.cpp:70-86): 6000 rounds of the wavefront
+    pipeline in one launch, 8-bit depth / 16-bit sample fields of the path record at their intended range."""
+    from vkrt_amd.flat_scene import make_push_constants
+
+    W, H = 48, 32
+    cam = default_camera(W, H)
+    pc = make_push_constants(samples=100, depth=30, frame=0, lights_count=1)
+    ref, c = cornell_oracle.render(pc, cam, W, H, seed=9)
+    img = renderers["sah"].pathtrace(pc, cam, W, H, seed=9).cpu().numpy()
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert c["rays_closest"] > W * H * 100 * 3
