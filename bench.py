@@ -115,7 +115,9 @@ def main():
         pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
         r.pathtrace(pc, cam, W, H, seed=frame, flags=flags, shard=shard, image=image, stream=stream)
         if world > 1:
-            return gather_image(image if args.backend == "nccl" else image.cpu(), H, world, rank)
+            # one gather per frame, overlapped with the next frame's kernels (side stream); the timed region ends with a
+            # device-wide synchronisation, so the last gathered image is complete inside it
+            return gather_image(image if args.backend == "nccl" else image.cpu(), H, world, rank, overlap=args.backend == "nccl")
         return image
 
     def sync():
@@ -185,7 +187,7 @@ def main():
                             f"{lights} fallback lights, progressive frames",
                 "width": W, "height": H, "spp": args.spp, "depth": args.depth, "triangles": info["triangles"],
                 "bvh": args.build, "bvh_nodes": accel["node_count"], "bvh_depth": accel["max_depth"],
-                "parallelism": f"image strips x{world} (16 rows, round-robin) + all_gather" if world > 1 else "single GPU",
+                "parallelism": f"image strips x{world} (16 rows, round-robin) + all_gather per frame (overlapped with the next frame)" if world > 1 else "single GPU",
                 "rays_per_step": rays_total / args.steps,
             },
         }

@@ -58,3 +58,35 @@ def test_gloo_world2_gather_reassembles_image(tmp_path):
     assert np.array_equal(a[..., 0], xx) and np.array_equal(a[..., 1], yy)
     owner = (yy // 16) % world
     assert np.array_equal(a[..., 2], owner)
+
+
+@pytest.mark.gpu
+def test_overlapped_gather_on_rccl_single_rank():
+    """The side-stream path of ImageGatherer with the real RCCL backend (one rank is all a 1-GPU box allows): the gather
+    of frame f overlaps whatever the caller enqueues next, buffers are not reused before the previous gather finished, and
+    after wait() the image is the local strips of the frame that was gathered."""
+    import torch
+    import torch.distributed as dist
+
+    from vkrt_amd.sharding import ImageGatherer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        H, W = 1080, 1920
+        g = ImageGatherer(H, W, 1, 0, torch.device("cuda:0"))
+        local = torch.zeros((H, W, 4), device="cuda:0")
+        for f in range(5):
+            local.fill_(float(f + 1))                     # "frame f"
+            full = g.gather(local, overlap=True)
+            local.mul_(0.5)                               # the caller goes on modifying its buffer at once
+            big = torch.randn(4096, 4096, device="cuda:0") @ torch.randn(4096, 4096, device="cuda:0")  # next frame's work
+            g.wait()
+            assert torch.all(full == float(f + 1)).item(), f
+        full = g.gather(local, overlap=False)
+        assert torch.all(full == 2.5).item()
+        del big
+    finally:
+        dist.destroy_process_group()

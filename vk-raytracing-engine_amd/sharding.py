@@ -55,11 +55,49 @@ class ImageGatherer:
             dst.append(g)
         self.src = torch.from_numpy(np.concatenate(src)).to(device)
         self.dst = torch.from_numpy(np.concatenate(dst)).to(device)
+        self._side = self._ready = self._done = None
+        self._pending = False
 
-    def gather(self, local):
+    def gather(self, local, overlap=False):
+        """Gathers this frame.  overlap=False: the returned image is ordered on the current stream like any torch op.
+        overlap=True (device tensors): only the copy of the local strips is ordered on the current stream; the collective and
+        the un-interleave run on a side stream, so the next frame's kernels overlap them.  The image is complete after
+        `wait()` (or any device-wide synchronisation); the next call waits for the previous gather before reusing buffers."""
+        import torch
         import torch.distributed as dist
 
-        self.padded[: self.rows_local].copy_(local, non_blocking=True)
+        on_device = self.padded.is_cuda
+        if on_device and self._side is None:
+            self._side = torch.cuda.Stream(device=self.padded.device)
+            self._ready = torch.cuda.Event()
+            self._done = torch.cuda.Event()
+        if on_device:
+            main = torch.cuda.current_stream(self.padded.device)
+            if self._pending:
+                main.wait_event(self._done)  # the previous gather still reads `padded` / writes `full`
+            self.padded[: self.rows_local].copy_(local, non_blocking=True)
+            self._ready.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ready)
+                self._collect(dist)
+                self._done.record(self._side)
+            self._pending = True
+            if not overlap:
+                self.wait()
+        else:
+            self.padded[: self.rows_local].copy_(local)
+            self._collect(dist)
+        return self.full
+
+    def wait(self):
+        """Orders the current stream after the last gather."""
+        import torch
+
+        if self._pending:
+            torch.cuda.current_stream(self.padded.device).wait_event(self._done)
+            self._pending = False
+
+    def _collect(self, dist):
         if dist.get_backend(self.group) == "nccl":
             dist.all_gather_into_tensor(self.recv, self.padded, group=self.group)
         else:
@@ -67,20 +105,19 @@ class ImageGatherer:
             dist.all_gather(parts, self.padded, group=self.group)
         flat = self.recv.view(self.world * self.cap, *self.recv.shape[2:])
         self.full.index_copy_(0, self.dst, flat.index_select(0, self.src))
-        return self.full
 
 
 _gatherers = {}
 
 
-def gather_image(local, height, world_size, rank, strip_rows=STRIP_ROWS, group=None):
+def gather_image(local, height, world_size, rank, strip_rows=STRIP_ROWS, group=None, overlap=False):
     """all_gather the per-rank strip buffers and un-interleave into the full [H, W, 4] image.
     `local` is a torch tensor [rows_r, W, 4] on any device; every rank returns the full image (a buffer that the next
-    call with the same geometry overwrites)."""
+    call with the same geometry overwrites).  overlap=True: see ImageGatherer.gather."""
     if world_size <= 1:
         return local
     key = (height, local.shape[1], world_size, rank, str(local.device), local.dtype, strip_rows, id(group))
     g = _gatherers.get(key)
     if g is None:
         g = _gatherers[key] = ImageGatherer(height, local.shape[1], world_size, rank, local.device, local.dtype, strip_rows, group)
-    return g.gather(local)
+    return g.gather(local, overlap=overlap)
