@@ -124,9 +124,10 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
           T.y &= T.y - 1u;
           const unsigned s = T.x + i;
-          const float4 a = tris[s * VKRT_TRI_QUADS + 0];
-          const float4 b = tris[s * VKRT_TRI_QUADS + 1];
-          const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+          const float4* __restrict__ tp = tris + (size_t)s * VKRT_TRI_QUADS;
+          const float4 a = tp[0];
+          const float4 b = tp[1];
+          const float4 c = tp[2];
           if(COUNT)
           {
             tc.tris++;

@@ -50,11 +50,12 @@ template <bool COUNT>
 VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child, f3 o, f3 id, unsigned octinv, bool px, bool py, bool pz, float tmin,
                                float bestT_in, uint2& G, uint2& T, TravCount& tc)
 {
-  const float4 q0 = nodes[child * VKRT_WNODE_QUADS + 0];
-  const float4 q1 = nodes[child * VKRT_WNODE_QUADS + 1];
-  const float4 q2 = nodes[child * VKRT_WNODE_QUADS + 2];
-  const float4 q3 = nodes[child * VKRT_WNODE_QUADS + 3];
-  const float4 q4 = nodes[child * VKRT_WNODE_QUADS + 4];
+  const float4* __restrict__ np = nodes + (size_t)child * VKRT_WNODE_QUADS;  // one 64-bit address, four immediate offsets
+  const float4 q0 = np[0];
+  const float4 q1 = np[1];
+  const float4 q2 = np[2];
+  const float4 q3 = np[3];
+  const float4 q4 = np[4];
   if(COUNT)
   {
     tc.nodes++;
@@ -152,9 +153,10 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     if(--S.steps == 0u)
       return false;
     const unsigned s = T.x + i;
-    const float4 a = tris[s * VKRT_TRI_QUADS + 0];
-    const float4 b = tris[s * VKRT_TRI_QUADS + 1];
-    const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+    const float4* __restrict__ tp = tris + (size_t)s * VKRT_TRI_QUADS;
+    const float4 a = tp[0];
+    const float4 b = tp[1];
+    const float4 c = tp[2];
     if(COUNT)
     {
       tc.tris++;
@@ -226,9 +228,10 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
     const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
     T.y &= T.y - 1u;
     const unsigned s = T.x + i;
-    const float4 a = tris[s * VKRT_TRI_QUADS + 0];
-    const float4 b = tris[s * VKRT_TRI_QUADS + 1];
-    const float4 c = tris[s * VKRT_TRI_QUADS + 2];
+    const float4* __restrict__ tp = tris + (size_t)s * VKRT_TRI_QUADS;
+    const float4 a = tp[0];
+    const float4 b = tp[1];
+    const float4 c = tp[2];
     if(COUNT)
     {
       tc.tris++;
