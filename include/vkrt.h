@@ -130,7 +130,8 @@ enum vkrt_trace_flags {
   /* Default reproduces raytrace.rgen:27: seed index = y*x + x.  This flag selects the
    * collision-free y*full_width + x instead (not parity). */
   VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1,
-  /* Count BVH nodes visited / triangles tested as well (slower instrumented kernel). */
+  /* Instrumented launch (slower): also count BVH nodes visited / triangles tested / wavefront steps and, in the default
+   * wavefront pipeline, the hit / diffuse-lobe / texture-tap tallies of the shading stage.  Rays and pixels are always counted. */
   VKRT_TRACE_COUNT_TRAVERSAL = 0x2,
   /* Record HIP events around every traversal-kernel launch of the frame (vkrt_last_trace_timing). */
   VKRT_TRACE_TIME_KERNELS = 0x4
@@ -145,9 +146,9 @@ typedef struct vkrt_trace_opts {
 typedef struct vkrt_counters {
   uint64_t rays_closest;   /* traceRayEXT calls of raytrace.rgen:64-75          */
   uint64_t rays_shadow;    /* traceRayEXT calls of raytrace.rgen:85-97          */
-  uint64_t hits;           /* raytrace.rchit invocations                        */
-  uint64_t diffuse_hits;   /* rchit invocations that took the diffuse lobe      */
-  uint64_t tex_taps;       /* texture() calls                                   */
+  uint64_t hits;           /* raytrace.rchit invocations                 (wavefront pipeline: with COUNT_TRAVERSAL) */
+  uint64_t diffuse_hits;   /* rchit invocations that took the diffuse lobe           (same)                    */
+  uint64_t tex_taps;       /* texture() calls                                         (same)                    */
   uint64_t pixels;         /* rgen invocations                                  */
   uint64_t nodes_visited;  /* only with VKRT_TRACE_COUNT_TRAVERSAL              */
   uint64_t tris_tested;    /* only with VKRT_TRACE_COUNT_TRAVERSAL              */

@@ -101,13 +101,20 @@ def test_config1_cornell_256_bit_identical(renderers, cornell_oracle, cornell_fl
     pc = make_push_constants(samples=1, depth=1, frame=0, lights_count=len(cornell_flat.lights))
     ref, cref = cornell_oracle.render(pc, cam, W, H, seed=0)
     r = renderers[kind]
+    from vkrt_amd import abi
+
     r.reset_counters()
-    img = r.pathtrace(pc, cam, W, H, seed=0).cpu().numpy()
+    img = r.pathtrace(pc, cam, W, H, seed=0, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL).cpu().numpy()  # instrumented: all tallies
     assert rmse(img, ref) < RMSE_TOL
     assert mismatch_fraction(img, ref) == 0.0
     c = r.counters()
     for k in ("rays_closest", "rays_shadow", "hits", "diffuse_hits", "tex_taps", "pixels"):
         assert c[k] == cref[k], k
+    r.reset_counters()
+    img2 = r.pathtrace(pc, cam, W, H, seed=0).cpu().numpy()  # plain launch: same image, rays and pixels still counted
+    c2 = r.counters()
+    assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
+    assert c2["rays_closest"] == cref["rays_closest"] and c2["rays_shadow"] == cref["rays_shadow"] and c2["pixels"] == cref["pixels"]
 
 
 def test_config2_shape_cornell_720p_multi_bounce(renderers, cornell_oracle, cornell_flat):
@@ -261,8 +268,10 @@ def test_atrium_small_textured_full_image(atrium_small, kind):
     import torch
 
     r = Renderer(flat, device=0, build=kind)
+    from vkrt_amd import abi
+
     r.reset_counters()
-    img = r.pathtrace(pc, cam, W, H, seed=21, image=torch.from_numpy(old.copy()).cuda()).cpu().numpy()
+    img = r.pathtrace(pc, cam, W, H, seed=21, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL, image=torch.from_numpy(old.copy()).cuda()).cpu().numpy()
     c = r.counters()
     r.close()
     assert rmse(img, ref) < RMSE_TOL

@@ -37,6 +37,7 @@
 #include "traverse_share.h"
 
 #define WF_BLOCK 256
+#define VKRT_FLAG_COUNT_WORK 2u  // = VKRT_TRACE_COUNT_TRAVERSAL (include/vkrt.h)
 #define VKRT_WF_SUBFRAMES_DEFAULT 2
 
 // ---- streams ---------------------------------------------------------------------------------------------------------
@@ -205,6 +206,9 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
   {
     B.ctrl[(par ^ 1) * 2 + 0] = 0u;  // next round's counts; this round's shade kernels claim slots from them
     B.ctrl[(par ^ 1) * 2 + 1] = 0u;
+    // every slot below the counts is traced exactly once: the ray counters of the launch are the stream counts
+    if(countC) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][0], (unsigned long long)countC);
+    if(countS) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][1], (unsigned long long)countS);
   }
   const unsigned nbC = (countC + TB - 1) / TB, nbS = (countS + TB - 1) / TB;
   if(blockIdx.x >= nbC + nbS)
@@ -213,7 +217,6 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
   const int type = anyHit ? 1 : 0;
   const unsigned qi = (anyHit ? blockIdx.x - nbC : blockIdx.x) * TB + threadIdx.x;
   const unsigned count = anyHit ? countS : countC;
-  unsigned nRays = 0;
   TravCount tc;
   __shared__ int shareLds[VKRT_SHARE_LDS_WORDS];
   if(WIDE && TB == 64 && P.sc.shareMinIdle != 0u && P.sc.triThreshold != 0u)  // launch-uniform
@@ -233,10 +236,7 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
     else
       traverse_wide8_share<COUNT, false>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
     if(valid)
-    {
       storeHit(P, B, par, type, qi, hit);
-      nRays = 1;
-    }
   }
   else if(qi < count)
   {
@@ -244,11 +244,13 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
     RayHit hit;
     traverse_any<COUNT, WIDE>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc);
     storeHit(P, B, par, type, qi, hit);
-    nRays = 1;
   }
-  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (TB / 64)];
-  const unsigned vals[10] = {anyHit ? 0u : nRays, anyHit ? nRays : 0u, 0, 0, 0, 0, tc.nodes, tc.tris, tc.waveNodeSteps, tc.waveTriSteps};
-  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, COUNT ? 10 : 2, red);
+  if(COUNT)
+  {
+    __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (TB / 64)];
+    const unsigned vals[10] = {0, 0, 0, 0, 0, 0, tc.nodes, tc.tris, tc.waveNodeSteps, tc.waveTriSteps};
+    blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 10, red);
+  }
 }
 
 // ---- shade, closest-hit results: rchit / rmiss, then shadow request or accumulation (heavy; few waves/SIMD) ---------
@@ -288,9 +290,12 @@ VKRT_DEV void shadeClosestBlock(const TraceParams& P, const WfBuffers& B, const 
     storeClosest(B, par ^ 1, slot, L);
   if(toShadow)
     storeShadow(B, par ^ 1, slot, L, contrib, nextWeight);
-  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
-  const unsigned vals[5] = {0, 0, st.hits, st.diffuse, st.taps};
-  blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 5, red);
+  if(P.flags & VKRT_FLAG_COUNT_WORK)  // launch-uniform: hit / lobe / texture-tap tallies are instrumentation, not needed for the ray rate
+  {
+    __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
+    const unsigned vals[5] = {0, 0, st.hits, st.diffuse, st.taps};
+    blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 5, red);
+  }
 }
 
 // ---- shade, shadow results: accumulate the segment (rgen:99-120), next sample or pixel store (light; many waves) --------
