@@ -11,11 +11,20 @@ struct LaneState
   Payload prd;
   f3 curWeight, hitValue, hitValues;
   f3 camOrigin;
-  uint32_t px, py;   // global pixel (gl_LaunchIDEXT.xy)
-  uint32_t lrow;     // row in the shard-local buffer
+  uint32_t px;       // global pixel column (gl_LaunchIDEXT.x)
+  uint32_t lrow;     // row in the shard-local buffer; gl_LaunchIDEXT.y = globalRow(P, lrow)
   int smpl;
   int stage;         // 0: next ray is the closest-hit ray, 1: next ray is the shadow ray
 };
+
+// shard-local row -> global row (include/vkrt.h vkrt_shard)
+VKRT_DEV uint32_t globalRow(const TraceParams& P, uint32_t lrow)
+{
+  if(P.stripRows == 0u)
+    return lrow;
+  const uint32_t s = lrow / P.stripRows, r = lrow % P.stripRows;
+  return (s * P.shardCount + P.shardIndex) * P.stripRows + r;
+}
 
 // raytrace.rgen:42-60 -- start sample `smpl` of the lane's pixel
 VKRT_DEV void startSample(const TraceParams& P, LaneState& L)
@@ -23,7 +32,8 @@ VKRT_DEV void startSample(const TraceParams& P, LaneState& L)
   const float r1 = rnd(L.prd.seed);
   const float r2 = rnd(L.prd.seed);
   const float jx = P.pc.frame == 0 ? 0.5f : r1, jy = P.pc.frame == 0 ? 0.5f : r2;
-  const float pcx = (float)L.px + jx, pcy = (float)L.py + jy;
+  const float pcx = (float)L.px + jx, pcy = (float)globalRow(P, L.lrow) + jy;  // (the global row is only needed here: two integer
+                                                                               //  divisions per sample when sharded, not per ray)
   const float inU = pcx / (float)P.fullW, inV = pcy / (float)P.fullH;
   const float dx = inU * 2.0f - 1.0f, dy = inV * 2.0f - 1.0f;
   float target[4], direction[4];
@@ -43,7 +53,7 @@ VKRT_DEV void startSample(const TraceParams& P, LaneState& L)
 // raytrace.rgen:27-30 -- bind a pixel to the lane
 VKRT_DEV void startPixel(const TraceParams& P, LaneState& L, uint32_t x, uint32_t y, uint32_t lrow)
 {
-  L.px = x; L.py = y; L.lrow = lrow;
+  L.px = x; L.lrow = lrow;  // (y == globalRow(P, lrow))
   const uint32_t index = (P.flags & 1u) ? (y * P.fullW + x) : (y * x + x);
   L.prd.seed = tea(index, P.seed);
   L.prd.isSpecular = false;
@@ -72,16 +82,6 @@ VKRT_DEV void storePixel(const TraceParams& P, const LaneState& L)
   else
     *dst = make_float4(res.x, res.y, res.z, 1.0f);
 }
-
-// shard-local row -> global row (include/vkrt.h vkrt_shard)
-VKRT_DEV uint32_t globalRow(const TraceParams& P, uint32_t lrow)
-{
-  if(P.stripRows == 0u)
-    return lrow;
-  const uint32_t s = lrow / P.stripRows, r = lrow % P.stripRows;
-  return (s * P.shardCount + P.shardIndex) * P.stripRows + r;
-}
-
 
 // After the closest-hit ray of the current segment: run rchit / rmiss (raytrace.rgen:64-75).
 // Returns true when a shadow ray has to be traced before the segment can be accumulated (rgen:79).

@@ -76,7 +76,7 @@ VKRT_DEV void loadCommon(const TraceParams& P, const WfBuffers& B, int parity, i
   L.prd.depth = flags & 0xffu; L.smpl = (int)((flags >> 8) & 0xffffu);
   L.prd.isSpecular = ((flags >> 25) & 1u) != 0u;
   L.hitValues = mk3(s2.x, s2.y, s2.z);
-  L.px = pix & 0xffffu; L.lrow = pix >> 16; L.py = globalRow(P, L.lrow);
+  L.px = pix & 0xffffu; L.lrow = pix >> 16;
   float origin[4];
   mat4MulVec4(P.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f, origin);  // rgen:30 (uniform; cheaper to recompute than to carry)
   L.camOrigin = mk3(origin[0], origin[1], origin[2]);
