@@ -245,7 +245,7 @@ def make_textures(rng, size=512):
     return tex
 
 
-def make_materials(rng, with_textures):
+def make_materials(rng, with_textures, emissive=False):
     n = 24
     m = np.zeros(n, MAT_DTYPE)
     for k in ("pbrBaseColorTexture", "metallicRoughnessTexture", "normalTexture", "emissiveTexture"):
@@ -271,22 +271,46 @@ def make_materials(rng, with_textures):
                 m["roughnessFactor"][i] = 1.0
             if i % 5 in (0, 3):
                 m["normalTexture"][i] = 6 + (i // 5) % 2
+    if emissive and with_textures:
+        # raytrace.rchit:83-87 / frag_shader.frag:190-192: emissiveFactor * texture(emissiveTexture) (an sRGB image,
+        # hello_vulkan.cpp:417-443), on dielectrics, on a mirror-like metal (so emission is also picked up at depth > 0,
+        # after a specular bounce) and on a normal-mapped material
+        for i, tex in ((0, 2), (3, 1), (5, 2), (12, 3), (13, 0), (16, 2), (21, 1)):
+            m["emissiveTexture"][i] = tex
+            m["emissiveFactor"][i] = (0.9, 0.55 + 0.02 * i, 0.2 + 0.03 * i)
+        m["emissiveFactor"][7] = (0.3, 0.05, 0.4)  # factor without a texture
     return m
 
 
-def build_atrium(target_triangles=262144, seed=1, with_textures=True):
+def mixed_lights():
+    """Scene lights of all three KHR_lights_punctual kinds as loadGltfLights maps them (hello_vulkan.cpp:207-223:
+    point 0, directional 1, spot 2; position = translation of the light node).  The path tracer's directLight only
+    evaluates type 0 (gltf.glsl:136-154); frag_shader.frag:205-208 treats every other type as directional."""
+    from vkrt_amd.flat_scene import LIGHT_DTYPE
+    L = np.zeros(5, LIGHT_DTYPE)
+    L[0] = ((1.0, 5.0, -1.33), (1.0, 0.95, 0.9), 50.0, 0)
+    L[1] = ((0.35, 1.0, 0.2), (1.0, 0.9, 0.7), 1.5, 1)     # directional
+    L[2] = ((-6.0, 9.0, 2.0), (0.6, 0.8, 1.0), 40.0, 2)    # spot
+    L[3] = ((8.0, 3.0, 0.5), (1.0, 0.4, 0.3), 30.0, 0)
+    L[4] = ((-9.0, 7.5, -6.5), (0.2, 1.0, 0.4), 25.0, 1)   # directional, from inside the building
+    return L
+
+
+def build_atrium(target_triangles=262144, seed=1, with_textures=True, variant=None):
     """Returns (FlatScene, info dict) with exactly `target_triangles` instanced triangles
-    (the tessellation scale is calibrated downwards, then small clutter tops the count up)."""
+    (the tessellation scale is calibrated downwards, then small clutter tops the count up).
+    variant="emissive_mixed_lights": same geometry; seven materials get an sRGB emissive texture and the file carries
+    five lights (2 point, 2 directional, 1 spot) instead of relying on the fallback lights."""
     d = float(np.sqrt(target_triangles / 360000.0))
     for _ in range(8):
-        flat, info = _build_atrium(target_triangles, seed, with_textures, d)
+        flat, info = _build_atrium(target_triangles, seed, with_textures, d, variant)
         if info["triangles"] <= target_triangles + 64:
             return flat, info
         d *= float(np.sqrt(target_triangles / info["triangles"])) * 0.985
     return flat, info
 
 
-def _build_atrium(target_triangles, seed, with_textures, d):
+def _build_atrium(target_triangles, seed, with_textures, d, variant=None):
     rng = np.random.default_rng(seed)
     def n_(x, lo=2):
         return max(lo, int(round(x * d)))
@@ -384,8 +408,10 @@ def _build_atrium(target_triangles, seed, with_textures, d):
         nd[i]["worldMatrix"] = np.asarray(M, np.float32).T.reshape(-1)
         nd[i]["primMesh"] = mi
     textures = make_textures(rng) if with_textures else []
+    assert variant in (None, "emissive_mixed_lights"), variant
+    emis = variant == "emissive_mixed_lights"
     flat = FlatScene(np.concatenate(P), np.concatenate(N), np.concatenate(T), np.concatenate(UV), np.concatenate(IDX),
-                     prims, make_materials(rng, with_textures), fallback_lights(), nd, textures)
+                     prims, make_materials(rng, with_textures, emissive=emis), mixed_lights() if emis else fallback_lights(), nd, textures)
     info = dict(triangles=flat.instanced_triangle_count, unique_triangles=int(sum(len(g["idx"]) // 3 for g, _ in meshes)),
                 prim_meshes=len(meshes), nodes=len(nodes), materials=24, textures=len(textures), seed=seed, tess_scale=d,
                 bounds=((X0, 0.0, Z0), (X1, Y1, Z1)), camera=DEFAULT_CAMERA)
