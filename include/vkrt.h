@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VKRT_ABI_VERSION 1
+#define VKRT_ABI_VERSION 2 /* 2: vkrt_scene_set_option / vkrt_reserve, vkrt_counters.traversal_faults */
 
 enum vkrt_status {
   VKRT_OK = 0,
@@ -155,6 +155,8 @@ typedef struct vkrt_counters {
   uint64_t wave_node_steps; /* COUNT_TRAVERSAL, wide8 layout: node steps per wavefront (one per 64 lanes);
                               nodes_visited / (64 * wave_node_steps) = lane efficiency of the node phase */
   uint64_t wave_tri_steps;  /* same for the triangle phase                        */
+  uint64_t traversal_faults; /* always counted: stack pushes dropped (stack sized from the builder's depth) + walks cut by the step
+                               bound.  Non-zero means a builder / traversal mismatch and possibly wrong pixels; tests assert 0. */
 } vkrt_counters;
 
 typedef struct vkrt_accel_info {
@@ -177,6 +179,25 @@ int         vkrt_device_count(void);     /* 0 without a HIP device */
 int  vkrt_scene_create(const vkrt_scene_desc* desc, int device, vkrt_scene** out);
 void vkrt_scene_destroy(vkrt_scene* scene);
 
+/* ---- per-scene execution options ------------------------------------------------------
+ * Scheduling knobs of the HIP path; none of them changes a pixel (tests/test_gpu_parity.py hashes every
+ * combination).  They are fields of the scene handle, not process globals.  Their INITIAL values are read once, at
+ * vkrt_scene_create, from the environment variables named below -- process-wide test hooks kept for A/B runs of
+ * unmodified binaries (bench.py, vkrt_render); vkrt_scene_set_option overrides them per handle.
+ * Options marked [build] are consumed by the next vkrt_accel_build, the others by the next vkrt_pathtrace. */
+enum vkrt_option {
+  VKRT_OPT_MODE            = 1, /* 1 = wavefront pipeline (default), 0 = one persistent megakernel (BVH2 only) [build]; env VKRT_MODE=mega */
+  VKRT_OPT_BVH_LAYOUT      = 2, /* 1 = 8-wide compressed nodes (default with the wavefront pipeline), 0 = BVH2 [build]; env VKRT_BVH=bvh2 */
+  VKRT_OPT_WF_SUBFRAMES    = 3, /* independent sub-frames of a launch on internal streams, 1..8 (default 2); env VKRT_WF_SUBFRAMES */
+  VKRT_OPT_WF_TRAV_BLOCK   = 4, /* threads per traversal workgroup: 64 (default), 128, 256; env VKRT_WF_TRAV_BLOCK */
+  VKRT_OPT_WF_SHARE        = 5, /* idle lanes of a traversal wave needed before they adopt subtrees, 0 = off (default 16) [build]; env VKRT_WF_SHARE */
+  VKRT_OPT_TRI_THRESHOLD   = 6, /* lanes with pending triangles before a wave tests them, 0 = test at once (default 1) [build]; env VKRT_TRI_THRESHOLD */
+  VKRT_OPT_WF_SHARE_PERIOD = 7, /* sharing attempted on steps with (step & mask) == mask (default 0 = every step) [build]; env VKRT_WF_SHARE_PERIOD */
+  VKRT_OPT_WF_SHARE_FLAGS  = 8  /* bit 0: lanes with an empty stack also donate a pending child of their current group [build]; env VKRT_WF_SHARE_FLAGS */
+};
+int vkrt_scene_set_option(vkrt_scene* scene, int option, int value);
+int vkrt_scene_get_option(const vkrt_scene* scene, int option, int* value);
+
 /* ---- acceleration structure (replaces createBottomLevelASGltf :1001-1011 and
  *      createTopLevelAsGltf :1031-1047) ------------------------------------------- */
 int vkrt_accel_build(vkrt_scene* scene, uint32_t build_flags, void* hip_stream);
@@ -185,10 +206,16 @@ int vkrt_accel_get_info(const vkrt_scene* scene, vkrt_accel_info* out);
 /* ---- path trace (replaces HelloVulkan::pathtrace :1423-1448 = one
  *      vkCmdTraceRaysKHR over raytrace.rgen/.rchit/.rmiss/raytraceShadow.rmiss) ---- */
 uint32_t vkrt_shard_rows(const vkrt_shard* shard); /* rows of the shard's buffer */
+/* Sizes the per-scene working set (path-record streams of the wavefront pipeline, internal streams and events) for
+ * launches of this shard geometry, like the reference allocates its offscreen images at start-up and on resize
+ * (createOffscreenRender, hello_vulkan.cpp:637-665).  After vkrt_reserve a vkrt_pathtrace of the same or a smaller
+ * shard never allocates and never synchronises with the host.  Without it the first launch (and any launch larger
+ * than every earlier one) grows the working set lazily: one hipStreamSynchronize + hipMalloc inside that call. */
+int vkrt_reserve(vkrt_scene* scene, const vkrt_shard* shard, void* hip_stream);
 /* Asynchronous like the command-buffer recording it replaces: returns after enqueueing.  All work is ordered after what
  * was enqueued on `hip_stream` before the call and complete before anything enqueued on it afterwards (the library may
- * run parts of a frame on internal streams that fork from and join `hip_stream` through events; no host
- * synchronisation happens inside the call).  pc->frame > 0 blends into the image the caller kept from the previous
+ * run parts of a frame on internal streams that fork from and join `hip_stream` through events).  No host
+ * synchronisation happens inside the call once the working set is large enough (vkrt_reserve above).  pc->frame > 0 blends into the image the caller kept from the previous
  * frame (raytrace.rgen:136-145), so the image buffer is caller-owned and persistent.  Calls on one scene handle must
  * be serialised by the caller. */
 int vkrt_pathtrace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(vkrt_amd.LIB_PATH)
     for s in abi.VKRT_SYMBOLS:
         assert hasattr(lib, s), s
-    assert lib.vkrt_abi_version() == 1
+    assert lib.vkrt_abi_version() == abi.VKRT_ABI_VERSION
 
 
 def test_argument_validation_and_no_cpu_fallback(cornell_flat):

@@ -28,6 +28,33 @@ def test_algorithmic_bytes_fixture_and_formula():
     assert oracle_py.algorithmic_bytes(c, frame_gt0=True) == oracle_py.algorithmic_bytes(c) + 16 * 5
 
 
+def test_default_sizes_follow_baseline_configs():
+    """N = 1 -> config 3 (1920x1080); N > 1 -> config 4 (one 3840x2160 frame, strong scaling) unless --weak."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "(3840, 2160) if world > 1 else (1920, 1080)" in src and '"strong" if world > 1' in src
+
+
+def test_product_path_of_bench_does_not_touch_the_oracle():
+    """Only the cpu_baseline leg may import from oracle/ (the camera comes from the product's host library)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head, leg = src.split("# ---- CPU oracle on a bounded sample", 1)
+    assert "import oracle_py" not in head and 'os.path.join(ROOT, "oracle")' not in head and "camera_np" not in src
+    assert "import oracle_py" in leg and "host_py.global_uniforms" in head
+
+
+def test_round2_bench_line_roofline_is_a_fraction():
+    import pytest
+
+    path = os.path.join(ROOT, "profiles", "r02_bench.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-2 bench line committed yet")
+    d = json.loads(open(path).read())
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["issue"]["peak"] > 0 and (r["issue"]["frac"] is None or 0 < r["issue"]["frac"] <= 1.0)
+    assert "contract" in r and "builds" in d["config"] and d["config"]["source_hash"]
+
+
 def test_committed_bench_line_follows_contract():
     path = os.path.join(ROOT, "profiles", "r01_bench.json")
     if not os.path.exists(path):

@@ -357,14 +357,15 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
-           "--rehearse-on-one-gpu", "--triangles", "20000", "--width", "640", "--height", "360", "--spp", "2", "--depth", "3"]
+           "--rehearse-on-one-gpu", "--weak", "--triangles", "20000", "--width", "640", "--height", "360", "--spp", "2", "--depth", "3"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2
-    assert d["config"]["width"] * d["config"]["height"] > 640 * 360 * 1.9  # 2x the pixels for 2 ranks
+    assert d["config"]["width"] * d["config"]["height"] > 640 * 360 * 1.9  # --weak: 2x the pixels for 2 ranks
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2 and d["config"]["imbalance_max_over_mean"] >= 1.0
 
 
 def _coincident_layers_scene(layers=5, n=12):
@@ -669,3 +670,40 @@ def test_ui_maximum_samples_and_depth(renderers, cornell_oracle):
     img = renderers["sah"].pathtrace(pc, cam, W, H, seed=9).cpu().numpy()
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     assert c["rays_closest"] > W * H * 100 * 3
+
+
+def test_scene_options_are_per_handle_and_do_not_change_pixels(atrium_small):
+    """vkrt_scene_set_option (include/vkrt.h): several handles with different scheduling options live in ONE process and all
+    render the same image; traversal_faults stays 0 everywhere; vkrt_reserve sizes the working set up front."""
+    import hashlib
+
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer, VkrtError
+    from vkrt_amd.sharding import make_shard
+
+    flat, info, camkw = atrium_small
+    W, H = 384, 216
+    cam = default_camera(W, H, **camkw)
+    variants = [{}, {abi.VKRT_OPT_WF_SUBFRAMES: 1}, {abi.VKRT_OPT_WF_SUBFRAMES: 3}, {abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 1},
+                {abi.VKRT_OPT_WF_SHARE: 4, abi.VKRT_OPT_WF_SHARE_FLAGS: 1}, {abi.VKRT_OPT_WF_TRAV_BLOCK: 256}, {abi.VKRT_OPT_BVH_LAYOUT: 0},
+                {abi.VKRT_OPT_TRI_THRESHOLD: 0, abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_MODE: 0}]
+    rs = [Renderer(flat, device=0, build="sah", options=v) for v in variants]
+    assert rs[1].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 1 and rs[0].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 2
+    with pytest.raises(VkrtError):
+        rs[0].set_option(abi.VKRT_OPT_WF_TRAV_BLOCK, 100)
+    with pytest.raises(VkrtError):
+        rs[0].set_option(99, 1)
+    hashes = []
+    for r in rs:
+        r.reserve(make_shard(W, H, 1, 0))
+        img = None
+        for f in range(2):
+            img = r.pathtrace(make_push_constants(samples=2, depth=6, frame=f, lights_count=len(flat.lights)), cam, W, H, seed=40 + f, image=img)
+        hashes.append(hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest())
+        assert r.counters()["traversal_faults"] == 0
+    modes = [r.last_trace_timing()["mode"] for r in rs]
+    for r in rs:
+        r.close()
+    assert modes[0] == "wavefront" and modes[-1] == "megakernel"
+    assert len(set(hashes)) == 1, dict(zip(map(str, variants), hashes))

@@ -22,6 +22,28 @@ if glob.glob(os.path.join(src, "stats_pipelined", "*", "*kernel_stats.csv")):
     shutil.copy(newest(os.path.join(src, "stats_pipelined", "*", "*kernel_stats.csv")), os.path.join(prof, f"{tag}_kernel_stats_pipelined.csv"))
 
 
+def bench_line(logname):
+    """The JSON line bench.py printed in a profiling pass: names the sources and the workload the counters belong to."""
+    try:
+        line = [l for l in open(os.path.join(src, logname)) if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception:
+        return None
+
+
+def tie(out, logname, dom_key_per_launch):
+    """Adds source_hash / workload / per-ray figures so bench.py can tell a stale summary from a fresh one."""
+    b = bench_line(logname)
+    if not b or "roofline" not in b:
+        return
+    out["source_hash"] = b["config"]["source_hash"]
+    out["workload"] = b["config"]["workload_key"]
+    out["rays_per_launch"] = b["roofline"]["rays_per_launch"]
+    for k_launch, k_ray in dom_key_per_launch:
+        if k_launch in out:
+            out[k_ray] = out[k_launch] / out["rays_per_launch"]
+
+
 def per_kernel(dirname, counter):
     f = newest(os.path.join(src, dirname, "*", "*counter_collection.csv"))
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
@@ -53,6 +75,10 @@ if dom:
     out["dominant_kernel"] = dom
     out["hbm_bytes_per_launch"] = out["kernels"][dom]["read_bytes_per_launch_x2"] + out["kernels"][dom]["write_bytes_per_launch"]
     out["hbm_bytes_per_launch_raw"] = out["kernels"][dom]["read_bytes_per_launch_raw"] + out["kernels"][dom]["write_bytes_per_launch"]
+    out["read_bytes_per_launch_raw"] = out["kernels"][dom]["read_bytes_per_launch_raw"]
+    out["write_bytes_per_launch"] = out["kernels"][dom]["write_bytes_per_launch"]
+    tie(out, "pmc_fetch.log", [("hbm_bytes_per_launch", "hbm_bytes_per_ray"), ("read_bytes_per_launch_raw", "read_bytes_per_ray_raw"),
+                               ("write_bytes_per_launch", "write_bytes_per_ray")])
 json.dump(out, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
 # VALU issue rate of the dominant kernel (the resource that actually binds it): wave-instructions per launch
 if glob.glob(os.path.join(src, "pmc_valu", "*", "*counter_collection.csv")):
@@ -68,5 +94,6 @@ if glob.glob(os.path.join(src, "pmc_valu", "*", "*counter_collection.csv")):
     if d:
         issue["dominant_kernel"] = d
         issue["valu_wave_instr_per_launch"] = issue["kernels"][d]["valu_wave_instr_per_launch"]
+        tie(issue, "pmc_valu.log", [("valu_wave_instr_per_launch", "valu_wave_instr_per_ray")])
     json.dump(issue, open(os.path.join(prof, "pmc_issue.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])

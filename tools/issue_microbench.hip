@@ -1,44 +1,96 @@
-// issue_microbench.hip -- VALU issue-rate calibration for gfx950 (roofline.issue.peak of bench.py).
-// Independent instruction streams of one opcode class, K waves per SIMD (K blocks of 256 threads per CU, pinned by
-// LDS size: K blocks fit a CU, K+1 do not), cycles per wave-instruction per SIMD from s_memtime stamps around the loop,
-// shader clock from s_memtime / s_memrealtime (100 MHz), co-residency check from the spread of the start stamps.
-// hipcc --offload-arch=gfx950.
-//   ./issue_microbench > profiles/r02_issue_microbench.json
+// issue_microbench.hip -- VALU issue-rate calibration for gfx950 (roofline.issue.peak of bench.py, DESIGN.md section 6).
+// One opcode per kernel, 8 independent register streams per wave, K waves per SIMD (K blocks of 256 threads per CU,
+// pinned by LDS size: K blocks fit a CU, K + 1 do not).  Reported per opcode and K: chip-wide wave-instructions per
+// second inside the kernel (first start stamp to last end stamp, s_memrealtime at 100 MHz), the same from hipEvents, and
+// the shader clock the waves saw (s_memtime / s_memrealtime).  hipcc -O3 --offload-arch=gfx950.
+//   tools/build/issue_microbench > profiles/r02_issue_microbench.json
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <vector>
-#include <algorithm>
-#define ITERS 2048
-#define UNROLL 32  // wave-instructions per loop body (4 x 8 independent registers)
-#define X8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+#define ITERS 1024
+// asm operands: %0 float stream, %1 uint stream, %2 64-bit pair stream (read-write); %3 / %4 loop-invariant floats, %5 invariant pair
+// clang-format off
+#define OPS(_) \
+  _(0,  "v_fma_f32",            1, "v_fma_f32 %0, %0, %3, %4") \
+  _(1,  "v_mul_f32",            1, "v_mul_f32 %0, %0, %3") \
+  _(2,  "v_add_f32",            1, "v_add_f32 %0, %0, %3") \
+  _(3,  "v_fmac_f32",           1, "v_fmac_f32 %0, %3, %4") \
+  _(4,  "v_max_f32",            1, "v_max_f32 %0, %0, %3") \
+  _(5,  "v_min_f32",            1, "v_min_f32 %0, %0, %3") \
+  _(6,  "v_max3_f32",           1, "v_max3_f32 %0, %0, %3, %4") \
+  _(7,  "v_min3_f32",           1, "v_min3_f32 %0, %0, %3, %4") \
+  _(8,  "v_med3_f32",           1, "v_med3_f32 %0, %0, %3, %4") \
+  _(9,  "v_cvt_f32_ubyte1",     1, "v_cvt_f32_ubyte1 %0, %1") \
+  _(10, "v_cvt_f32_ubyte0",     1, "v_cvt_f32_ubyte0 %0, %1") \
+  _(11, "v_cvt_f32_u32",        1, "v_cvt_f32_u32 %0, %1") \
+  _(12, "v_cvt_f32_u32_sdwa_byte1", 1, "v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1") \
+  _(13, "v_cmp_lt_f32+v_cndmask_b32", 2, "v_cmp_lt_f32 %2, %3, %4\n v_cndmask_b32 %0, %0, %1, %2") \
+  _(14, "v_cmp_lt_f32",         1, "v_cmp_lt_f32 %2, %0, %3") \
+  _(15, "v_cndmask_b32",        1, "v_cndmask_b32 %0, %0, %1, vcc") \
+  _(16, "v_mov_b32",            1, "v_mov_b32 %0, %1") \
+  _(17, "v_and_b32",            1, "v_and_b32 %1, %1, %3") \
+  _(18, "v_or_b32",             1, "v_or_b32 %1, %1, %3") \
+  _(19, "v_lshrrev_b32",        1, "v_lshrrev_b32 %1, 1, %1") \
+  _(20, "v_add_u32",            1, "v_add_u32 %1, %1, %3") \
+  _(21, "v_bfe_u32",            1, "v_bfe_u32 %1, %1, 8, 8") \
+  _(22, "v_and_or_b32",         1, "v_and_or_b32 %1, %1, %3, %4") \
+  _(23, "v_lshl_or_b32",        1, "v_lshl_or_b32 %1, %1, 1, %3") \
+  _(24, "v_perm_b32",           1, "v_perm_b32 %1, %1, %3, %4") \
+  _(25, "v_bcnt_u32_b32",       1, "v_bcnt_u32_b32 %1, %1, %3") \
+  _(26, "v_pk_fma_f32",         1, "v_pk_fma_f32 %2, %2, %5, %5") \
+  _(27, "v_pk_mul_f32",         1, "v_pk_mul_f32 %2, %2, %5") \
+  _(28, "v_rcp_f32",            1, "v_rcp_f32 %0, %0") \
+  _(29, "v_sqrt_f32",           1, "v_sqrt_f32 %0, %0") \
+  _(30, "v_mul_lo_u32",         1, "v_mul_lo_u32 %1, %1, %3") \
+  _(31, "v_mad_u32_u24",        1, "v_mad_u32_u24 %1, %1, %3, %4") \
+  _(32, "v_mov_b32_sdwa_byte1_preserve", 1, "v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2") \
+  _(33, "v_or_b32_sdwa_byte",   1, "v_or_b32_sdwa %0, %1, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD") \
+  _(34, "v_lshlrev_b32_sdwa",   1, "v_lshlrev_b32_sdwa %1, %3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_1") \
+  _(35, "v_max_i32",            1, "v_max_i32 %1, %1, %3") \
+  _(36, "v_min_u32",            1, "v_min_u32 %1, %1, %3") \
+  _(37, "v_max3_i32",           1, "v_max3_i32 %1, %1, %3, %4") \
+  _(38, "v_sub_f32",            1, "v_sub_f32 %0, %0, %3") \
+  _(39, "v_xor_b32",            1, "v_xor_b32 %1, %1, %3") \
+  _(40, "v_lshlrev_b32_var",    1, "v_lshlrev_b32 %1, %3, %1") \
+  _(41, "v_bitop3_b32",         1, "v_bitop3_b32 %1, %1, %3, %4 bitop3:0x6c") \
+  _(42, "v_or3_b32",            1, "v_or3_b32 %1, %1, %3, %4") \
+  _(43, "v_add3_u32",           1, "v_add3_u32 %1, %1, %3, %4") \
+  _(44, "v_cvt_f32_f16",        1, "v_cvt_f32_f16 %0, %1") \
+  _(45, "v_cvt_u32_f32",        1, "v_cvt_u32_f32 %1, %0") \
+  _(46, "v_ldexp_f32",          1, "v_ldexp_f32 %0, %0, %3") \
+  _(47, "v_fma_mix_f32",        1, "v_fma_mix_f32 %0, %0, %3, %4")
+// clang-format on
 template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, unsigned long long* cyc, float s)
 {
   extern __shared__ int pin[];
-  float v[8]; unsigned u[8];
+  float v[8]; unsigned u[8]; double p[4], q[4]; unsigned long long m[8];
   for(int i = 0; i < 8; i++) { v[i] = s + threadIdx.x + i; u[i] = threadIdx.x * 2654435761u + i; }
+  for(int i = 0; i < 4; i++) { p[i] = s + i; q[i] = s * 0.25 + i; }
   const float a = s * 0.5f, b = s + 0.25f;
-  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
   for(int it = 0; it < ITERS; it++)
   {
 #pragma unroll
     for(int r = 0; r < 4; r++)
     {
-#define FMA(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(a), "v"(b));
-#define CVT(i) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(v[i]) : "v"(u[i]));
-#define CMPSEL(i) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %0, %3, vcc" : "+v"(v[i]) : "v"(a), "v"(b), "v"(u[i]) : "vcc");
-#define MAXF(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
-#define INTOP(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(a));
-#define PKFMA(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(double*)&v[i & 6]) : "v"(*(const double*)&u[(i + 2) & 6]));
-#define RCP(i) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i]));
-#define MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(a));
-      if(OP == 0) { X8(FMA) } if(OP == 1) { X8(CVT) } if(OP == 2) { X8(CMPSEL) } if(OP == 3) { X8(MAXF) }
-      if(OP == 4) { X8(INTOP) } if(OP == 5) { X8(PKFMA) } if(OP == 6) { X8(RCP) } if(OP == 7) { X8(MUL) }
+#define GEN(id, name, n, text)                                                                                                        \
+  if(OP == id)                                                                                                                        \
+  {                                                                                                                                   \
+    _Pragma("unroll") for(int i = 0; i < 8; i++)                                                                                      \
+      if(id == 13 || id == 14)                                                                                                          \
+        asm volatile(text : "+v"(v[i]), "+v"(u[i]), "=s"(m[i]) : "v"(a), "v"(b));                                                     \
+      else if(id == 26 || id == 27) /* the 64-bit pair stream only where it is used (declared pair writes get s_nop padding) */        \
+        asm volatile(text : "+v"(v[i]), "+v"(u[i]), "+v"(p[i & 3]) : "v"(a), "v"(b), "v"(q[i & 3]));                                   \
+      else /* no vcc clobber either: a declared vcc write makes the compiler pad every statement with s_nop */                        \
+        asm volatile(text : "+v"(v[i]), "+v"(u[i]) : "v"(p[i & 3]), "v"(a), "v"(b));                                                   \
+  }
+      OPS(GEN)
+#undef GEN
     }
   }
-  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-  float acc = 0; for(int i = 0; i < 8; i++) acc += v[i] + (float)u[i];
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float acc = 0; for(int i = 0; i < 8; i++) acc += v[i] + (float)u[i] + (float)p[i & 3] + ((OP == 13 || OP == 14) ? (float)m[i] : 0.0f);
   out[blockIdx.x * 256 + threadIdx.x] = acc + (float)pin[0];
   if((threadIdx.x & 63) == 0)
   {
@@ -49,39 +101,40 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, uns
 template <int OP> static void run(const char* name, int perBody, bool last)
 {
   const int CU = 256; float* out; unsigned long long* cyc;
-  hipMalloc(&out, CU * 8 * 256 * 4); hipMalloc(&cyc, CU * 8 * 4 * 8 * 3);
+  (void)hipMalloc(&out, CU * 8 * 256 * 4); (void)hipMalloc(&cyc, CU * 8 * 4 * 8 * 3);
   printf("  \"%s\": {", name);
-  const int ks[6] = {1, 2, 3, 4, 5, 8};
-  for(int q = 0; q < 6; q++)
+  const int ks[4] = {1, 2, 5, 8};
+  for(int q = 0; q < 4; q++)
   {
     const int k = ks[q]; const size_t lds = (150 * 1024 / k) & ~1023;  // k blocks fit one CU (<= 150 KB), k + 1 do not (> 160 KB)
-    hipFuncSetAttribute((const void*)k_issue<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipFuncSetAttribute((const void*)k_issue<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k_issue<OP><<<CU * k, 256, lds>>>(out, cyc, 1.0f);
-    hipEventRecord(e0); k_issue<OP><<<CU * k, 256, lds>>>(out, cyc, 1.0f); hipEventRecord(e1); hipDeviceSynchronize();
-    float ms; hipEventElapsedTime(&ms, e0, e1);
+    (void)hipDeviceSynchronize();  // the timed launch starts on an idle chip: every block is resident from the start
+    (void)hipEventRecord(e0); k_issue<OP><<<CU * k, 256, lds>>>(out, cyc, 1.0f); (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const size_t nw = (size_t)CU * k * 4;
-    std::vector<unsigned long long> h(nw * 3); hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> h(nw * 3); (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     double mean = 0, real = 0; unsigned long long s0 = ~0ull, s1 = 0, re = 0;
     for(size_t w = 0; w < nw; w++)
     {
       mean += (double)h[3 * w]; real += (double)(h[3 * w + 2] - h[3 * w + 1]);
       s0 = std::min(s0, h[3 * w + 1]); s1 = std::max(s1, h[3 * w + 1]); re = std::max(re, h[3 * w + 2]);
     }
-    mean /= nw; real /= nw;
     const double instr = (double)ITERS * 4 * 8 * perBody;  // wave-instructions per wave
-    printf("%s\"%d\": {\"cyc_per_instr_per_simd\": %.3f, \"G_wave_instr_per_s\": %.1f, \"G_wave_instr_per_s_in_kernel\": %.1f, \"clock_GHz\": %.3f, "
-           "\"start_spread_us\": %.1f, \"kernel_us\": %.1f}", q ? ", " : "", k, mean / (instr * k), instr * nw / (ms * 1e-3) / 1e9,
-           instr * nw / ((double)(re - s0) * 1e-8) / 1e9, mean / real * 0.1, (double)(s1 - s0) * 0.01, (double)(re - s0) * 0.01);
+    const double rate = instr * nw / ((double)(re - s0) * 1e-8) / 1e9, clk = mean / real * 0.1;
+    printf("%s\"%d\": {\"G_wave_instr_per_s\": %.1f, \"G_wave_instr_per_s_hipevent\": %.1f, \"clock_GHz\": %.3f, \"cyc_per_instr_per_simd\": %.2f, "
+           "\"start_spread_us\": %.1f, \"kernel_us\": %.1f}", q ? ", " : "", k, rate, instr * nw / (ms * 1e-3) / 1e9, clk, 1024.0 * clk / rate,
+           (double)(s1 - s0) * 0.01, (double)(re - s0) * 0.01);
   }
   printf("}%s\n", last ? "" : ",");
-  hipFree(out); hipFree(cyc);
+  (void)hipFree(out); (void)hipFree(cyc);
 }
 int main()
 {
-  printf("{\n \"note\": \"waves/SIMD -> cycles (s_memtime) per wave64 instruction per SIMD and chip-wide rate (hipEvent wall time)\",\n");
-  run<0>("v_fma_f32", 1, false); run<7>("v_mul_f32", 1, false); run<1>("v_cvt_f32_ubyte1", 1, false); run<2>("v_cmp_lt_f32+v_cndmask_b32", 2, false);
-  run<3>("v_max_f32", 1, false); run<4>("v_and_or_b32", 1, false); run<5>("v_pk_fma_f32", 1, false); run<6>("v_rcp_f32", 1, true);
+  printf("{\n \"note\": \"per opcode: waves/SIMD -> chip-wide G wave64-instructions/s (in-kernel stamps; hipEvent), shader clock, cycles per instruction per SIMD\",\n");
+#define RUN(id, name, n, text) run<id>(name, n, id == 47);
+  OPS(RUN)
   printf("}\n");
   return 0;
 }

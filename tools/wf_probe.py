@@ -8,12 +8,12 @@ from vkrt_amd import abi
 from vkrt_amd.flat_scene import make_push_constants, uniforms_from_matrices
 from vkrt_amd.renderer import Renderer
 import atrium, camera_np
-W, H = 1920, 1080
+W, H = int(os.environ.get("PROBE_W", 1920)), int(os.environ.get("PROBE_H", 1080))
 flat, info = atrium.build_atrium(262144, seed=1)
 cam = uniforms_from_matrices(*camera_np.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA))
 r = Renderer(flat, device=0, build=os.environ.get("BUILD", "sah"))
 img = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-for spp, depth in ((1, 1), (1, 8), (4, 8)):
+for spp, depth in (((4, 8),) if os.environ.get("PROBE_QUICK") else ((1, 1), (1, 8), (4, 8))):
     pc = make_push_constants(samples=spp, depth=depth, frame=0, lights_count=8)
     for it in range(3):
         r.reset_counters()

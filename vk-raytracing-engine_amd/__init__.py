@@ -14,3 +14,18 @@ HOST_LIB_PATH = os.path.join(PKG_DIR, "libvkrt_host.so")
 
 from . import abi  # noqa: E402,F401
 from . import flat_scene  # noqa: E402,F401
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel / ABI sources: ties committed PMC summaries (profiles/pmc_*.json) to
+    the code they were measured on, so bench.py can refuse stale ones."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.h")) + glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip"))
+                   + glob.glob(os.path.join(PKG_DIR, "csrc", "*.cpp")) + glob.glob(os.path.join(REPO_ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

@@ -122,6 +122,7 @@ class Counters(C.Structure):
         ("tris_tested", c_u64),
         ("wave_node_steps", c_u64),
         ("wave_tri_steps", c_u64),
+        ("traversal_faults", c_u64),
     ]
 
     def as_dict(self):
@@ -167,6 +168,10 @@ VKRT_BUILD_SAH_HOST = 0x2
 VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1
 VKRT_TRACE_COUNT_TRAVERSAL = 0x2
 VKRT_TRACE_TIME_KERNELS = 0x4
+VKRT_ABI_VERSION = 2
+# vkrt_option
+VKRT_OPT_MODE, VKRT_OPT_BVH_LAYOUT, VKRT_OPT_WF_SUBFRAMES, VKRT_OPT_WF_TRAV_BLOCK = 1, 2, 3, 4
+VKRT_OPT_WF_SHARE, VKRT_OPT_TRI_THRESHOLD, VKRT_OPT_WF_SHARE_PERIOD, VKRT_OPT_WF_SHARE_FLAGS = 5, 6, 7, 8
 
 # every symbol include/vkrt.h declares (tests check the built library exports them all)
 VKRT_SYMBOLS = [
@@ -175,6 +180,9 @@ VKRT_SYMBOLS = [
     "vkrt_device_count",
     "vkrt_scene_create",
     "vkrt_scene_destroy",
+    "vkrt_scene_set_option",
+    "vkrt_scene_get_option",
+    "vkrt_reserve",
     "vkrt_accel_build",
     "vkrt_accel_get_info",
     "vkrt_shard_rows",
@@ -201,6 +209,12 @@ def declare_vkrt(lib):
     lib.vkrt_scene_create.restype = C.c_int
     lib.vkrt_scene_destroy.argtypes = [C.c_void_p]
     lib.vkrt_scene_destroy.restype = None
+    lib.vkrt_scene_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.vkrt_scene_set_option.restype = C.c_int
+    lib.vkrt_scene_get_option.argtypes = [C.c_void_p, C.c_int, P(C.c_int)]
+    lib.vkrt_scene_get_option.restype = C.c_int
+    lib.vkrt_reserve.argtypes = [C.c_void_p, P(Shard), C.c_void_p]
+    lib.vkrt_reserve.restype = C.c_int
     lib.vkrt_accel_build.argtypes = [C.c_void_p, c_u, C.c_void_p]
     lib.vkrt_accel_build.restype = C.c_int
     lib.vkrt_accel_get_info.argtypes = [C.c_void_p, P(AccelInfo)]

@@ -89,7 +89,11 @@ struct DevScene
   uint32_t triThreshold;      // wide8: lanes with pending triangles needed before a wave tests them (0 = test at once)
   uint32_t sharePeriodMask;   // work sharing is attempted on steps with (step & mask) == mask (0 = every step)
   uint32_t shareMinIdle;      // wide8, wavefront mode: idle lanes of a wave take over pending subtrees of busy lanes once this many are idle (0 = off)
+  uint32_t shareFlags;        // bit 0: lanes whose stack is empty also donate the farthest pending child of their current group
+  unsigned long long* faults; // sticky tally of dropped stack pushes + step-limit exits (a walk that was cut short); must stay 0
 };
+// a traversal could not keep a pending subtree (stack full) or ran into the step bound: the result may be wrong -> make it visible
+#define VKRT_TRAV_FAULT(sc) atomicAdd((sc).faults, 1ull)
 
 // Counter storage: 64 slots of 10 counters (padded to two 64-byte lines, order of vkrt_counters).  A workgroup
 // adds its block-reduced totals to slot (blockIdx % 64), so same-address atomic serialisation is

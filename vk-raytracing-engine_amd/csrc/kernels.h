@@ -29,7 +29,12 @@ struct WfAsync
 };
 size_t     vkrt_wf_state_bytes(uint32_t pathCapacity);
 void       vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B);
-hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing,
+struct WfOptions
+{
+  int subframes;  // VKRT_OPT_WF_SUBFRAMES
+  int travBlock;  // VKRT_OPT_WF_TRAV_BLOCK (64 / 128 / 256)
+};
+hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, bool count, hipStream_t stream, WfTiming* timing,
                                  const WfAsync* async);
 
 // hybrid mode (hybrid.hip)

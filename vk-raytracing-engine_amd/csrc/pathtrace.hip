@@ -175,18 +175,8 @@ __global__ void k_eval_math(int op, unsigned n, const float* a, const float* b, 
 }
 
 // ---- launch wrappers (called from vkrt_api.cpp) ------------------------------------------------------
-// MINW = minimum waves per SIMD the register allocator must allow (occupancy knob; variant 0 = default)
-static int g_variant = -1;
-static int pathtraceVariant()
-{
-  if(g_variant < 0)
-  {
-    const char* e = getenv("VKRT_MINWAVES");
-    g_variant = e ? atoi(e) : 3;  // 3 waves/SIMD measured +34% over the unconstrained build (profiles/r01_v1_*)
-  }
-  return g_variant;
-}
-
+// MINW = minimum waves per SIMD the register allocator must allow: 3 measured +34 % over the unconstrained build and
+// level with 4 (profiles/r01_experiments.md #2, #3), so the product build carries that one variant.
 hipError_t vkrt_launch_pathtrace(const TraceParams& P, unsigned gridBlocks, bool count, hipStream_t stream)
 {
   const size_t lds = (size_t)P.sc.stackCap * VKRT_BLOCK * sizeof(int);
@@ -194,13 +184,7 @@ hipError_t vkrt_launch_pathtrace(const TraceParams& P, unsigned gridBlocks, bool
   if(count)
     hipLaunchKernelGGL((k_pathtrace<true, 1>), g, b, lds, stream, P);
   else
-    switch(pathtraceVariant())
-    {
-      case 3: hipLaunchKernelGGL((k_pathtrace<false, 3>), g, b, lds, stream, P); break;
-      case 4: hipLaunchKernelGGL((k_pathtrace<false, 4>), g, b, lds, stream, P); break;
-      case 2: hipLaunchKernelGGL((k_pathtrace<false, 2>), g, b, lds, stream, P); break;
-      default: hipLaunchKernelGGL((k_pathtrace<false, 1>), g, b, lds, stream, P); break;
-    }
+    hipLaunchKernelGGL((k_pathtrace<false, 3>), g, b, lds, stream, P);
   return hipGetLastError();
 }
 
@@ -208,13 +192,7 @@ int vkrt_pathtrace_block_size() { return VKRT_BLOCK; }
 
 hipError_t vkrt_pathtrace_occupancy(size_t ldsBytes, int* blocksPerCU)
 {
-  switch(pathtraceVariant())
-  {
-    case 3: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 3>, VKRT_BLOCK, ldsBytes);
-    case 4: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 4>, VKRT_BLOCK, ldsBytes);
-    case 2: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 2>, VKRT_BLOCK, ldsBytes);
-    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 1>, VKRT_BLOCK, ldsBytes);
-  }
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 3>, VKRT_BLOCK, ldsBytes);
 }
 
 hipError_t vkrt_launch_trace_rays(const DevScene& sc, unsigned n, const float* o, const float* d, float tmin, float tmax, int anyHit,

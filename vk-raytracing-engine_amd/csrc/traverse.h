@@ -93,6 +93,7 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
     {
       if(--steps == 0u)
       {
+        VKRT_TRAV_FAULT(sc);
         cur = VKRT_TRAV_DONE;
         break;
       }
@@ -114,6 +115,8 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
           stk[sp * stride] = farC;
           sp++;
         }
+        else
+          VKRT_TRAV_FAULT(sc);
         cur = nearC;
       }
       else if(h0)
@@ -134,7 +137,10 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
     if(cur != VKRT_TRAV_DONE)
     {
       if(--steps == 0u)
+      {
+        VKRT_TRAV_FAULT(sc);
         break;
+      }
       const unsigned code = ~(unsigned)cur;
       const unsigned first = code >> 3, cnt = (code & 7u) + 1u;
       bool done = false;

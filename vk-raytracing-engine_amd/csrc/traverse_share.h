@@ -24,6 +24,16 @@ struct ShareRes
   float* v;
   int* donor;               // scratch of a sharing step: lane of the r-th donor
 };
+// The lanes of the sharing wave talk to each other through LDS (res.*, donor[]).  They run in lockstep, but the HIP memory
+// model does not know that: order every cross-lane write before the reads that depend on it with a wavefront-scope
+// release / acquire pair around a wave barrier (no instruction beyond the s_waitcnt the accesses need anyway; it stops
+// the compiler from caching or reordering the LDS accesses).
+VKRT_DEV void shareSync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 VKRT_DEV ShareRes shareRes(int* lds320)
 {
   ShareRes r;
@@ -47,6 +57,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
 
   res.key[lane] = ((unsigned long long)__float_as_uint(tmax) << 32) | 0xffffffffull;
   res.slot[lane] = -1; res.u[lane] = 0.0f; res.v[lane] = 0.0f;
+  shareSync();  // adopting lanes read res.*[owner] of other lanes
 
   int owner = lane;  // home lane of the ray this lane is working on
   f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
@@ -66,20 +77,34 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
     // ---- work sharing (every 4th step): idle lanes adopt the oldest pending node group of busy lanes ---------------------
     if((iter & sc.sharePeriodMask) == sc.sharePeriodMask && (unsigned)__popcll(~busyMask) >= shareMin)
     {
-      const unsigned long long donorMask = __ballot(busy && sp - sb >= 1), idleMask = ~busyMask;
+      // donors: lanes with a pending group on their stack give the oldest one (largest, farthest subtree); with shareFlags bit 0
+      // a lane whose stack is empty but whose current group still has two or more pending children gives the farthest of them
+      const bool giveStack = busy && sp - sb >= 1;
+      const bool giveChild = (sc.shareFlags & 1u) != 0u && busy && !giveStack && (G.y & 0xff000000u & ((G.y & 0xff000000u) - 1u)) != 0u;
+      const unsigned long long donorMask = __ballot(giveStack || giveChild), idleMask = ~busyMask;
       if(donorMask != 0ull)
       {
         const unsigned n = min((unsigned)__popcll(donorMask), (unsigned)__popcll(idleMask));
         const unsigned giveRank = (unsigned)__popcll(donorMask & below), takeRank = (unsigned)__popcll(idleMask & below);
-        const bool gives = busy && sp - sb >= 1 && giveRank < n;
+        const bool gives = (giveStack || giveChild) && giveRank < n;
         const bool takes = !busy && takeRank < n;
         uint2 e = make_uint2(0u, 0u);
         if(gives)
         {
-          e = stk[sb * stride];
-          sb++;
+          if(giveStack)
+          {
+            e = stk[sb * stride];
+            sb++;
+          }
+          else
+          {
+            const unsigned top = G.y & 0xff000000u, low = top & (0u - top);  // lowest pending bit = last in front-to-back order
+            e = make_uint2(G.x, low | (G.y & 0xffu));
+            G.y &= ~low;
+          }
           res.donor[giveRank] = lane;  // r-th donor feeds the r-th idle lane
         }
+        shareSync();
         const int src = takes ? res.donor[takeRank] : lane;
         const unsigned ex = (unsigned)__shfl((int)e.x, src), ey = (unsigned)__shfl((int)e.y, src);
         const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
@@ -105,16 +130,17 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
     bool found = false;  // this lane has a candidate hit to publish
     float ct = 0.0f, cu = 0.0f, cv = 0.0f;
     int cslot = -1, cgid = 0;
+    shareSync();  // results published in the previous step are visible to every lane of the ray
     if(busy)
     {
       float bt = tmax;
       int bg = -1;
       bool finished = false;
       if(ANYHIT)
-        finished = res.slot[owner] >= 0;  // somebody already found an occluder for this ray
+        finished = __hip_atomic_load(&res.slot[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >= 0;  // somebody already found an occluder for this ray
       else
       {
-        const unsigned long long k = res.key[owner];
+        const unsigned long long k = __hip_atomic_load(&res.key[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         bt = __uint_as_float((unsigned)(k >> 32));
         bg = (int)(unsigned)k;
       }
@@ -161,10 +187,15 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           const unsigned slot = (bitIdx - 24u) ^ octinv;
           const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
           G.y &= ~(1u << bitIdx);
-          if((G.y & 0xff000000u) && sp + nPost < cap)
+          if(G.y & 0xff000000u)
           {
-            stk[sp * stride] = G;
-            sp++;
+            if(sp + nPost < cap)
+            {
+              stk[sp * stride] = G;
+              sp++;
+            }
+            else
+              VKRT_TRAV_FAULT(sc);
           }
           uint2 Tn;
           w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bt, G, Tn, tc);
@@ -204,7 +235,10 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
         else if((G.y & 0xff000000u) == 0u && T.y == 0u && nPost == 0)
           finished = true;  // (sp == sb here: the refill above would have popped otherwise)
         else if(--steps == 0u)
+        {
+          VKRT_TRAV_FAULT(sc);
           finished = true;
+        }
       }
       if(finished)
         busy = false;  // (G, T and the stack indices are dead until the lane adopts new work)
@@ -213,18 +247,22 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
     if(found)
     {
       if(ANYHIT)
-        res.slot[owner] = cslot;
+        __hip_atomic_store(&res.slot[owner], cslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       else
       {
+        // (t bits, triangle id) is unique per candidate, so "the minimum is mine" identifies exactly one winner among the
+        // lanes publishing for this ray in this step; it alone writes the payload.  Keys only decrease.
         const unsigned long long mine = ((unsigned long long)__float_as_uint(ct) << 32) | (unsigned)cgid;
-        atomicMin(&res.key[owner], mine);
-        if(res.key[owner] == mine)
+        __hip_atomic_fetch_min(&res.key[owner], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        shareSync();  // every lane's minimum has been applied before anyone checks who won
+        if(__hip_atomic_load(&res.key[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == mine)
         {
           res.slot[owner] = cslot; res.u[owner] = cu; res.v[owner] = cv;
         }
       }
     }
   }
+  shareSync();
   hit.t = __uint_as_float((unsigned)(res.key[lane] >> 32)); hit.u = res.u[lane]; hit.v = res.v[lane]; hit.slot = res.slot[lane];
   if(ANYHIT)
     hit.t = tmax;

@@ -136,13 +136,21 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     const unsigned slot = (bitIdx - 24u) ^ octinv;
     const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
     G.y &= ~(1u << bitIdx);
-    if((G.y & 0xff000000u) && S.sp < cap)
+    if(G.y & 0xff000000u)
     {
-      stk[S.sp * stride] = G;
-      S.sp++;
+      if(S.sp < cap)
+      {
+        stk[S.sp * stride] = G;
+        S.sp++;
+      }
+      else
+        VKRT_TRAV_FAULT(sc);
     }
     if(--S.steps == 0u)
+    {
+      VKRT_TRAV_FAULT(sc);
       return false;
+    }
     w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, S.bestT, G, T, tc);
   }
   // triangles of this node that the ray's boxes touched
@@ -151,7 +159,10 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
     const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
     T.y &= T.y - 1u;
     if(--S.steps == 0u)
+    {
+      VKRT_TRAV_FAULT(sc);
       return false;
+    }
     const unsigned s = T.x + i;
     const float4* __restrict__ tp = tris + (size_t)s * VKRT_TRI_QUADS;
     const float4 a = tp[0];
@@ -270,10 +281,15 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
       const unsigned slot = (bitIdx - 24u) ^ octinv;
       const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
       G.y &= ~(1u << bitIdx);
-      if((G.y & 0xff000000u) && sp + nPost < cap)
+      if(G.y & 0xff000000u)
       {
-        stk[sp * stride] = G;
-        sp++;
+        if(sp + nPost < cap)
+        {
+          stk[sp * stride] = G;
+          sp++;
+        }
+        else
+          VKRT_TRAV_FAULT(sc);
       }
       uint2 Tn;
       w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bestT, G, Tn, tc);
@@ -322,7 +338,10 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
     if(!hasG && T.y == 0u && nPost == 0)
       break;
     if(--steps == 0u)
+    {
+      VKRT_TRAV_FAULT(sc);
       break;
+    }
   }
   hit.t = bestT; hit.u = bestU; hit.v = bestV; hit.slot = bestSlot;
 }

@@ -22,6 +22,7 @@
 
 #define VKRT_TRI_THRESHOLD_DEFAULT 1
 #define VKRT_WF_SHARE_DEFAULT 16
+#define VKRT_WF_SHARE_FLAGS_DEFAULT 0
 #include "lbvh.h"
 
 namespace {
@@ -79,6 +80,9 @@ struct vkrt_scene
   std::vector<hipEvent_t> wfEvents;
   WfTiming wfTiming{};
   bool wfTimed = false;
+  // execution options (include/vkrt.h vkrt_option); index = option id
+  int opt[9] = {0, 1, 1, 2, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT};
+  bool wavefront = true;  // execution mode the acceleration structure was built for (opt[VKRT_OPT_MODE] at vkrt_accel_build)
 };
 
 namespace {
@@ -143,16 +147,36 @@ int validate(const vkrt_scene_desc* d)
   return VKRT_OK;
 }
 
-// execution mode: wavefront pipeline (default) or the single persistent megakernel (VKRT_MODE=mega)
-bool useWavefront()
+// execution mode: wavefront pipeline (default) or the single persistent megakernel
+bool useWavefront(const vkrt_scene* s) { return s->opt[VKRT_OPT_MODE] == 1; }
+
+int clampOption(int option, int v)
 {
-  static int mode = -1;
-  if(mode < 0)
+  switch(option)
   {
-    const char* e = getenv("VKRT_MODE");
-    mode = (e && !strcmp(e, "mega")) ? 0 : 1;
+    case VKRT_OPT_MODE: case VKRT_OPT_BVH_LAYOUT: return v ? 1 : 0;
+    case VKRT_OPT_WF_SUBFRAMES: return std::max(1, std::min(VKRT_WF_MAX_SUBFRAMES, v));
+    case VKRT_OPT_WF_TRAV_BLOCK: return v == 256 ? 256 : v == 128 ? 128 : 64;
+    case VKRT_OPT_WF_SHARE: return std::max(0, std::min(64, v));
+    case VKRT_OPT_TRI_THRESHOLD: return std::max(0, std::min(65, v));
+    case VKRT_OPT_WF_SHARE_PERIOD: return std::max(0, std::min(255, v));
+    case VKRT_OPT_WF_SHARE_FLAGS: return v & 1;
   }
-  return mode == 1;
+  return v;
+}
+
+// Initial option values: the process-wide test hooks documented in include/vkrt.h, read once per scene handle.
+void optionsFromEnvironment(vkrt_scene* s)
+{
+  const char* e;
+  if((e = getenv("VKRT_MODE")) && !strcmp(e, "mega")) s->opt[VKRT_OPT_MODE] = 0;
+  if((e = getenv("VKRT_BVH")) && !strcmp(e, "bvh2")) s->opt[VKRT_OPT_BVH_LAYOUT] = 0;
+  const struct { const char* name; int option; } ints[] = {{"VKRT_WF_SUBFRAMES", VKRT_OPT_WF_SUBFRAMES}, {"VKRT_WF_TRAV_BLOCK", VKRT_OPT_WF_TRAV_BLOCK},
+                                                          {"VKRT_WF_SHARE", VKRT_OPT_WF_SHARE}, {"VKRT_TRI_THRESHOLD", VKRT_OPT_TRI_THRESHOLD},
+                                                          {"VKRT_WF_SHARE_PERIOD", VKRT_OPT_WF_SHARE_PERIOD}, {"VKRT_WF_SHARE_FLAGS", VKRT_OPT_WF_SHARE_FLAGS}};
+  for(const auto& k : ints)
+    if((e = getenv(k.name)))
+      s->opt[k.option] = clampOption(k.option, atoi(e));
 }
 
 void freeAccel(vkrt_scene* s)
@@ -167,6 +191,31 @@ void freeAccel(vkrt_scene* s)
 int setDevice(const vkrt_scene* s)
 {
   HIP_TRY(hipSetDevice(s->device));
+  return VKRT_OK;
+}
+
+// Working set of the wavefront pipeline for `paths` path records (whole 8x8 tiles of the shard) + the internal streams
+// of the sub-frame pipeline.  Growing it is the only place a trace call may synchronise with the host (vkrt_reserve).
+int ensureWorkingSet(vkrt_scene* s, uint32_t paths, hipStream_t stream)
+{
+  if(!s->wfMem || s->wf.capacity < paths)
+  {
+    HIP_TRY(hipStreamSynchronize(stream));  // an earlier frame may still be using the smaller buffer
+    if(s->wfMem) (void)hipFree(s->wfMem);
+    s->wfMem = nullptr;
+    HIP_TRY(hipMalloc(&s->wfMem, vkrt_wf_state_bytes(paths)));
+    vkrt_wf_carve(s->wfMem, paths, &s->wf);
+  }
+  if(s->wfAsync.count == 0)
+  {
+    HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.fork, hipEventDisableTiming));
+    for(int j = 0; j < VKRT_WF_MAX_SUBFRAMES; j++)
+    {
+      HIP_TRY(hipStreamCreateWithFlags(&s->wfAsync.streams[j], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.join[j], hipEventDisableTiming));
+    }
+    s->wfAsync.count = VKRT_WF_MAX_SUBFRAMES;
+  }
   return VKRT_OK;
 }
 
@@ -200,6 +249,7 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, ndev);
   vkrt_scene* s = new vkrt_scene();
   s->device = device;
+  optionsFromEnvironment(s);
   auto bail = [&](int code) {
     vkrt_scene_destroy(s);
     return code;
@@ -306,6 +356,7 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   D.triThreshold = 0;
   D.shareMinIdle = 0;
   D.sharePeriodMask = 0;
+  D.shareFlags = 0;
 
   void* p = nullptr;
   if(hipMalloc(&p, 64) != hipSuccess) return bail(fail(VKRT_ERR_OUT_OF_MEMORY, "hipMalloc(work counter)"));
@@ -314,6 +365,7 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   if(hipMalloc(&p, sizeof(DevCounters)) != hipSuccess) return bail(fail(VKRT_ERR_OUT_OF_MEMORY, "hipMalloc(counters)"));
   s->allocs.push_back(p);
   s->counters = (DevCounters*)p;
+  D.faults = &s->counters->v[0][10];
   if(hipMemset(s->counters, 0, sizeof(DevCounters)) != hipSuccess) return bail(fail(VKRT_ERR_HIP, "hipMemset(counters)"));
   if(hipEventCreate(&s->evStart) != hipSuccess || hipEventCreate(&s->evStop) != hipSuccess)
     return bail(fail(VKRT_ERR_HIP, "hipEventCreate"));
@@ -345,6 +397,47 @@ void vkrt_scene_destroy(vkrt_scene* s)
   delete s;
 }
 
+int vkrt_scene_set_option(vkrt_scene* s, int option, int value)
+{
+  if(!s)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if(option < VKRT_OPT_MODE || option > VKRT_OPT_WF_SHARE_FLAGS)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+  if(clampOption(option, value) != value)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "option %d: value %d out of range", option, value);
+  s->opt[option] = value;
+  return VKRT_OK;
+}
+
+int vkrt_scene_get_option(const vkrt_scene* s, int option, int* value)
+{
+  if(!s || !value)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(option < VKRT_OPT_MODE || option > VKRT_OPT_WF_SHARE_FLAGS)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+  *value = s->opt[option];
+  return VKRT_OK;
+}
+
+int vkrt_reserve(vkrt_scene* s, const vkrt_shard* shard, void* hip_stream)
+{
+  if(!s || !shard)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(shard->full_width == 0 || shard->full_height == 0)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "empty launch size");
+  if(shard->shard_count > 1 && (shard->strip_rows == 0 || shard->shard_index >= shard->shard_count))
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "bad shard");
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  const uint64_t tiles = (uint64_t)((shard->full_width + 7) / 8) * ((vkrt_shard_rows(shard) + 7) / 8);
+  if(tiles * 64 >= 0xFFFFFFFFull)
+    return fail(VKRT_ERR_UNSUPPORTED, "launch too large");
+  if(tiles == 0 || s->opt[VKRT_OPT_MODE] != 1)
+    return VKRT_OK;  // the megakernel keeps its state in registers / LDS
+  return ensureWorkingSet(s, (uint32_t)tiles * 64u, (hipStream_t)hip_stream);
+}
+
 int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
 {
   if(!s)
@@ -363,15 +456,15 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   const auto t0 = std::chrono::steady_clock::now();
   s->info = vkrt_accel_info{};
   s->info.build_flags = wantLbvh ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
+  s->wavefront = useWavefront(s);
 
   if(wantSah)
   {
     std::vector<vkrt::FlatTri> tris;
     vkrt::flatten_instances(s->positions.data(), s->indices.data(), s->primMeshes.data(), s->nodes.data(),
                             (uint32_t)s->nodes.size(), tris);
-    // wide8 (compressed 8-wide) is the trace-optimised layout; the megakernel and VKRT_BVH=bvh2 keep BVH2
-    const char* envBvh = getenv("VKRT_BVH");
-    const bool wide = useWavefront() && !(envBvh && !strcmp(envBvh, "bvh2"));
+    // wide8 (compressed 8-wide) is the trace-optimised layout; the megakernel and VKRT_OPT_BVH_LAYOUT = 0 keep BVH2
+    const bool wide = useWavefront(s) && s->opt[VKRT_OPT_BVH_LAYOUT] == 1;
     std::vector<float> packed;
     const void* nodeData = nullptr;
     size_t nodeBytesUsed = 0;
@@ -433,8 +526,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   }
   else
   {
-    const char* envBvh = getenv("VKRT_BVH");
-    const bool wide = useWavefront() && !(envBvh && !strcmp(envBvh, "bvh2"));
+    const bool wide = useWavefront(s) && s->opt[VKRT_OPT_BVH_LAYOUT] == 1;
     vkrt::LbvhResult r;
     // GPU radix-tree build (Morton codes, sort, Karras hierarchy, bottom-up fit).  For the trace-optimised layout the
     // binary tree keeps one triangle per leaf and is collapsed into wide8 nodes by the same SAH-optimal DP as the SAH
@@ -515,19 +607,17 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   s->dev.triThreshold = 0;
   s->dev.shareMinIdle = 0;
   s->dev.sharePeriodMask = 0;
+  s->dev.shareFlags = 0;
   if(s->dev.layout == 1)
   {
     // triangle postponing (traverse_wide.h): lanes with pending triangles before a wave tests them; 0 = immediate
-    const char* e = getenv("VKRT_TRI_THRESHOLD");
-    const int v = e ? atoi(e) : VKRT_TRI_THRESHOLD_DEFAULT;
-    s->dev.triThreshold = (uint32_t)(v < 0 ? 0 : (v > 65 ? 65 : v));
+    s->dev.triThreshold = (uint32_t)s->opt[VKRT_OPT_TRI_THRESHOLD];
     if(s->dev.triThreshold != 0u)
       s->dev.stackCap += 2 * VKRT_W8_MAX_POSTPONED;  // room for parked triangle groups (uint2 entries)
     // work sharing inside a traversal wave (traverse_share.h): minimum number of idle lanes before they take over subtrees
-    const char* sh = getenv("VKRT_WF_SHARE");
-    const int shv = sh ? atoi(sh) : VKRT_WF_SHARE_DEFAULT;
-    s->dev.shareMinIdle = (uint32_t)(shv < 0 ? 0 : (shv > 64 ? 64 : shv));
-    s->dev.sharePeriodMask = getenv("VKRT_WF_SHARE_PERIOD") ? (uint32_t)atoi(getenv("VKRT_WF_SHARE_PERIOD")) : 0u;
+    s->dev.shareMinIdle = (uint32_t)s->opt[VKRT_OPT_WF_SHARE];
+    s->dev.sharePeriodMask = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_PERIOD];
+    s->dev.shareFlags = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS];
   }
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
   if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)
@@ -612,19 +702,12 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   P.tileFirst = 0;
 
   const bool count = (P.flags & VKRT_TRACE_COUNT_TRAVERSAL) != 0;
-  if(useWavefront())
+  if(s->wavefront)
   {
     if(P.fullW > 65535u || P.localRows > 65535u || pc->samples > 65535)
       return fail(VKRT_ERR_UNSUPPORTED, "wavefront mode packs pixel coordinates / sample index in 16 bits");
-    const uint32_t need = P.tileCount * 64u;
-    if(!s->wfMem || s->wf.capacity < need)
-    {
-      HIP_TRY(hipStreamSynchronize(stream));
-      if(s->wfMem) (void)hipFree(s->wfMem);
-      s->wfMem = nullptr;
-      HIP_TRY(hipMalloc(&s->wfMem, vkrt_wf_state_bytes(need)));
-      vkrt_wf_carve(s->wfMem, need, &s->wf);
-    }
+    if((rc = ensureWorkingSet(s, P.tileCount * 64u, stream)) != VKRT_OK)
+      return rc;
     WfTiming* timing = nullptr;
     if(P.flags & VKRT_TRACE_TIME_KERNELS)
     {
@@ -641,18 +724,10 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
     }
     s->wfTimed = timing != nullptr;
     HIP_TRY(hipEventRecord(s->evStart, stream));
-    if(s->wfAsync.count == 0)
-    {
-      // internal streams for the sub-frame pipeline (wavefront.hip); created once per scene
-      HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.fork, hipEventDisableTiming));
-      for(int j = 0; j < VKRT_WF_MAX_SUBFRAMES; j++)
-      {
-        HIP_TRY(hipStreamCreateWithFlags(&s->wfAsync.streams[j], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.join[j], hipEventDisableTiming));
-      }
-      s->wfAsync.count = VKRT_WF_MAX_SUBFRAMES;
-    }
-    HIP_TRY(vkrt_launch_wavefront(P, s->wf, s->cuCount, count, stream, timing, &s->wfAsync));
+    WfOptions wo;
+    wo.subframes = s->opt[VKRT_OPT_WF_SUBFRAMES];
+    wo.travBlock = s->opt[VKRT_OPT_WF_TRAV_BLOCK];
+    HIP_TRY(vkrt_launch_wavefront(P, s->wf, wo, count, stream, timing, &s->wfAsync));
     HIP_TRY(hipEventRecord(s->evStop, stream));
     s->timed = true;
     return VKRT_OK;
@@ -789,12 +864,12 @@ int vkrt_counters_read(vkrt_scene* s, vkrt_counters* out)
   HIP_TRY(hipDeviceSynchronize());
   DevCounters h;
   HIP_TRY(hipMemcpy(&h, s->counters, sizeof h, hipMemcpyDeviceToHost));
-  unsigned long long t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for(int sl = 0; sl < VKRT_COUNTER_SLOTS; sl++)
-    for(int k = 0; k < 10; k++) t[k] += h.v[sl][k];
+    for(int k = 0; k < 11; k++) t[k] += h.v[sl][k];
   out->rays_closest = t[0]; out->rays_shadow = t[1]; out->hits = t[2]; out->diffuse_hits = t[3];
   out->tex_taps = t[4]; out->pixels = t[5]; out->nodes_visited = t[6]; out->tris_tested = t[7];
-  out->wave_node_steps = t[8]; out->wave_tri_steps = t[9];
+  out->wave_node_steps = t[8]; out->wave_tri_steps = t[9]; out->traversal_faults = t[10];
   return VKRT_OK;
 }
 
@@ -818,7 +893,7 @@ int vkrt_last_trace_timing(vkrt_scene* s, vkrt_trace_timing* out)
   memset(out, 0, sizeof *out);
   HIP_TRY(hipEventSynchronize(s->evStop));
   HIP_TRY(hipEventElapsedTime(&out->total_ms, s->evStart, s->evStop));
-  out->mode = useWavefront() ? 1u : 0u;
+  out->mode = s->wavefront ? 1u : 0u;
   if(s->wfTimed)
   {
     for(int k = 0; k < s->wfTiming.used; k++)
@@ -829,7 +904,7 @@ int vkrt_last_trace_timing(vkrt_scene* s, vkrt_trace_timing* out)
     }
     out->traverse_launches = (uint32_t)s->wfTiming.used;
   }
-  else if(!useWavefront())
+  else if(!s->wavefront)
   {
     out->traverse_ms = out->total_ms;
     out->traverse_launches = 1;

@@ -38,7 +38,6 @@
 
 #define WF_BLOCK 256
 #define VKRT_FLAG_COUNT_WORK 2u  // = VKRT_TRACE_COUNT_TRAVERSAL (include/vkrt.h)
-#define VKRT_WF_SUBFRAMES_DEFAULT 2
 
 // ---- streams ---------------------------------------------------------------------------------------------------------
 // Four streams [parity][type] (type 0 = paths whose next ray is the closest-hit ray, 1 = the shadow ray), each
@@ -351,19 +350,13 @@ void vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B)
   B->capacity = pathCapacity;
 }
 
-static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, bool count, hipStream_t stream, WfTiming* timing);
+static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsigned travBlock, bool count, hipStream_t stream, WfTiming* timing);
 
-hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int cuCount, bool count, hipStream_t stream, WfTiming* timing,
+hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, bool count, hipStream_t stream, WfTiming* timing,
                                  const WfAsync* async)
 {
-  (void)cuCount;
-  static int want = -1;
-  if(want < 0)
-  {
-    const char* ev = getenv("VKRT_WF_SUBFRAMES");
-    want = ev ? atoi(ev) : VKRT_WF_SUBFRAMES_DEFAULT;
-    want = std::max(1, std::min(VKRT_WF_MAX_SUBFRAMES, want));
-  }
+  const int want = std::max(1, std::min(VKRT_WF_MAX_SUBFRAMES, opt.subframes));
+  const unsigned travBlock = opt.travBlock == 256 ? 256u : opt.travBlock == 128 ? 128u : 64u;
   // per-kernel timing wants the kernels one after another; tiny frames are not worth splitting
   int n = (timing || !async) ? 1 : std::min(want, async->count);
   n = (int)std::min<uint32_t>((uint32_t)std::max(n, 1), std::max(1u, P.tileCount / 256u));
@@ -371,7 +364,7 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int c
   {
     TraceParams Q = P;
     Q.tileFirst = 0;
-    return launchSubframe(Q, B, count, stream, timing);
+    return launchSubframe(Q, B, travBlock, count, stream, timing);
   }
   hipError_t e = hipEventRecord(async->fork, stream);
   if(e != hipSuccess)
@@ -387,14 +380,14 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, int c
     Bj.planes = B.planes + (size_t)4 * WF_PLANES * ((size_t)t0 * 64u);
     Bj.capacity = Q.tileCount * 64u;
     if((e = hipStreamWaitEvent(async->streams[j], async->fork, 0)) != hipSuccess) return e;
-    if((e = launchSubframe(Q, Bj, count, async->streams[j], nullptr)) != hipSuccess) return e;
+    if((e = launchSubframe(Q, Bj, travBlock, count, async->streams[j], nullptr)) != hipSuccess) return e;
     if((e = hipEventRecord(async->join[j], async->streams[j])) != hipSuccess) return e;
     if((e = hipStreamWaitEvent(stream, async->join[j], 0)) != hipSuccess) return e;
   }
   return hipSuccess;
 }
 
-static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, bool count, hipStream_t stream, WfTiming* timing)
+static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsigned travBlock, bool count, hipStream_t stream, WfTiming* timing)
 {
   const unsigned work = P.tileCount * 64u;
   hipError_t e = hipMemsetAsync(B.ctrl, 0, 64, stream);
@@ -410,13 +403,6 @@ static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, bool 
   const int rounds = 2 * P.pc.samples * P.pc.depth;
   if(timing)
     timing->used = 0;
-  static unsigned travBlock = 0;
-  if(travBlock == 0)
-  {
-    const char* ev = getenv("VKRT_WF_TRAV_BLOCK");
-    const int v = ev ? atoi(ev) : 64;
-    travBlock = v == 256 ? 256u : v == 128 ? 128u : 64u;
-  }
   // closest + shadow entries never exceed the number of paths; +2 blocks for the two partial tails.
   // One wavefront per workgroup by default: a finished wave frees its slot and LDS without waiting for three others.
   const dim3 tg((work + travBlock - 1) / travBlock + 2), tb(travBlock);

@@ -24,7 +24,7 @@ def load_library():
             raise RuntimeError(f"{LIB_PATH} missing: build it with __graft_entry__.build() "
                                "(there is no CPU fallback for the ray-tracing path)")
         _lib = abi.declare_vkrt(C.CDLL(LIB_PATH))
-        if _lib.vkrt_abi_version() != 1:
+        if _lib.vkrt_abi_version() != abi.VKRT_ABI_VERSION:
             raise RuntimeError("libvkrt.so ABI version mismatch")
     return _lib
 
@@ -43,16 +43,36 @@ def whole_image_shard(width, height):
 
 
 class Renderer:
-    def __init__(self, flat, device=0, build="sah"):
+    def __init__(self, flat, device=0, build="sah", options=None):
+        """options: {abi.VKRT_OPT_*: value} applied before the build (per-handle execution options, include/vkrt.h)."""
+        import time
+
         self.lib = load_library()
         self.device = device
         desc, keep = flat.to_desc()
         h = C.c_void_p()
+        t0 = time.perf_counter()
         _check(self.lib.vkrt_scene_create(C.byref(desc), device, C.byref(h)), "vkrt_scene_create")
+        self.upload_ms = (time.perf_counter() - t0) * 1e3  # scene upload (hello_vulkan.cpp:353-381), host wall time
         self._h = h
         del keep
         self.lights_count = int(flat.lights.shape[0])
-        self.build(build)
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+        if build:
+            self.build(build)
+
+    def set_option(self, option, value):
+        _check(self.lib.vkrt_scene_set_option(self._h, int(option), int(value)), "vkrt_scene_set_option")
+
+    def get_option(self, option):
+        v = C.c_int()
+        _check(self.lib.vkrt_scene_get_option(self._h, int(option), C.byref(v)), "vkrt_scene_get_option")
+        return int(v.value)
+
+    def reserve(self, shard, stream=None):
+        """Size the working set for launches of this shard geometry (no allocation / host sync inside later pathtrace calls)."""
+        _check(self.lib.vkrt_reserve(self._h, C.byref(shard), C.c_void_p(stream.cuda_stream) if stream is not None else None), "vkrt_reserve")
 
     def build(self, kind="sah"):
         flags = {"sah": abi.VKRT_BUILD_SAH_HOST, "lbvh": abi.VKRT_BUILD_LBVH_GPU}[kind]
