@@ -241,12 +241,24 @@ VKRT_DEV f3 xformNormal(const DevInstance& in, f3 n)
   return r;
 }
 
-// raytrace.rchit:31-219
+// raytrace.rchit:31-219 in three pieces, so that the wavefront shading stage can regroup hits by lobe between them
+// (wavefront.hip shadeClosestBlock); run back to back (closestHitShaderInst) they are the shader as written.
+//   closestHitFront  rchit:34-125   attribute fetch + interpolation, the four texture() taps, normal mapping, material
+//   closestHitLobe   rchit:127-131  ratio from the unclamped metalness, the lobe draw r1 < ratio
+//   closestHitTail   rchit:126-216  clamps, diffuse (NEE + cosine sample) or specular (GGX sample) branch, payload outputs
+struct HitMid
+{
+  f3 worldPos, N, tangent, binormal, V, baseColor, emittance;
+  float metalU, roughU;  // UNCLAMPED metalness / roughness (ratio and directLight use them as fetched)
+  unsigned retap;        // texture() calls computePBR_BRDF would re-issue (counted, not fetched twice)
+};
+
 // `ts` = sc.triShade[hit.slot] (vertex indices + material), fetched by the caller (the wavefront traversal kernel
 // leaves it in the path record next to the hit).
 // `instId` = the instance the hit triangle belongs to (third word of its last triangle-record quad).  hit.slot is not read.
-VKRT_DEV void closestHitShaderInst(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, const uint32_t instId, const uint4 ts,
-                                   f3 worldRayDir, Payload& prd, ShadeStats& st)
+// Reads prd.depth / prd.isSpecular (emission rule, rchit:83); writes nothing to prd.
+VKRT_DEV void closestHitFront(const DevScene& sc, const RayHit& hit, const uint32_t instId, const uint4 ts, f3 worldRayDir, const Payload& prd,
+                              ShadeStats& st, HitMid& mid)
 {
   st.hits++;
   // rchit:34-50 (PrimMeshInfo lookup, three index fetches, vertexOffset, max(0, materialIndex)) is resolved once
@@ -338,20 +350,36 @@ VKRT_DEV void closestHitShaderInst(const DevScene& sc, const PushConstantRay& pc
     metalness *= t.z;
   }
 
+  mid.worldPos = worldPos; mid.N = texNormal; mid.tangent = tangent; mid.binormal = binormal;
+  mid.V = normalize3(-worldRayDir);
+  mid.baseColor = baseColor; mid.emittance = emittance;
+  mid.metalU = metalness; mid.roughU = roughness;
+  mid.retap = (mat.pbrBaseColorTexture > -1 ? 1u : 0u) + (mat.metallicRoughnessTexture > -1 ? 1u : 0u);
+}
+
+// rchit:127,130-131: true = diffuse lobe.  Advances prd.seed by the one draw.
+VKRT_DEV bool closestHitLobe(const HitMid& mid, Payload& prd)
+{
+  const float ratio = 0.5f * (1.0f - mid.metalU);  // rchit:127 (before the clamps)
+  const float r1 = rnd(prd.seed);
+  return r1 < ratio;
+}
+
+VKRT_DEV void closestHitTail(const DevScene& sc, const PushConstantRay& pc, const HitMid& mid, const bool diffuse, Payload& prd, ShadeStats& st)
+{
+  const f3 worldPos = mid.worldPos, texNormal = mid.N, tangent = mid.tangent, binormal = mid.binormal, V = mid.V, N = mid.N;
+  const f3 baseColor = mid.baseColor;
+  f3 emittance = mid.emittance;
+  const float metalU = mid.metalU, roughU = mid.roughU;  // unclamped values, as directLight re-derives them
+  const unsigned retap = mid.retap;
+  const float ratio = 0.5f * (1.0f - metalU);
+  const float roughness = glsl_clamp(roughU, 0.01f, 0.99f);  // rchit:128-129
+  const float metalness = glsl_clamp(metalU, 0.01f, 0.99f);
   const f3 rayOrigin = worldPos;
   f3 rayDirection;
   float pdf;
   f3 BRDF;
-  const f3 V = normalize3(-worldRayDir);
-  const f3 N = texNormal;
-
-  const float metalU = metalness, roughU = roughness;  // unclamped values, as directLight re-derives them
-  const unsigned retap = (mat.pbrBaseColorTexture > -1 ? 1u : 0u) + (mat.metallicRoughnessTexture > -1 ? 1u : 0u);
-  const float ratio = 0.5f * (1.0f - metalness);  // rchit:127 (before the clamps)
-  roughness = glsl_clamp(roughness, 0.01f, 0.99f);
-  metalness = glsl_clamp(metalness, 0.01f, 0.99f);
-  const float r1 = rnd(prd.seed);
-  if(r1 < ratio)
+  if(diffuse)
   {
     st.diffuse++;
     prd.isSpecular = false;
@@ -398,6 +426,15 @@ VKRT_DEV void closestHitShaderInst(const DevScene& sc, const PushConstantRay& pc
   prd.rayDirection = rayDirection;
   prd.hitValue = emittance;
   prd.weight = BRDF * cosTheta / pdf;
+}
+
+VKRT_DEV void closestHitShaderInst(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, const uint32_t instId, const uint4 ts,
+                                   f3 worldRayDir, Payload& prd, ShadeStats& st)
+{
+  HitMid mid;
+  closestHitFront(sc, hit, instId, ts, worldRayDir, prd, st, mid);
+  const bool diffuse = closestHitLobe(mid, prd);
+  closestHitTail(sc, pc, mid, diffuse, prd, st);
 }
 
 VKRT_DEV void closestHitShader(const DevScene& sc, const PushConstantRay& pc, const RayHit& hit, const uint4 ts, f3 worldRayDir, Payload& prd,

@@ -22,7 +22,7 @@
 
 #define VKRT_TRI_THRESHOLD_DEFAULT 1
 #define VKRT_WF_SHARE_DEFAULT 16
-#define VKRT_WF_SHARE_FLAGS_DEFAULT 0
+#define VKRT_WF_SHARE_FLAGS_DEFAULT 1
 #include "lbvh.h"
 
 namespace {

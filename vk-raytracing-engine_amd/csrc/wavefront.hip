@@ -253,6 +253,11 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
 }
 
 // ---- shade, closest-hit results: rchit / rmiss, then shadow request or accumulation (heavy; few waves/SIMD) ---------
+// (Regrouping the 256 results of a workgroup by lobe through LDS between the hit shader's front half and its diffuse / specular
+// tail -- closestHitFront / closestHitLobe / closestHitTail in shade.h -- so that a wave runs one branch only was built and
+// measured in round 2: bit-identical images, ~30 % fewer VALU instructions, no change in kernel time (5.94 vs 5.91 ms per
+// 4-spp frame): the stage is bound by its stream traffic to HBM and the latency of its gathers, not by issue.  Removed again;
+// profiles/r02_experiments.md #52.)
 VKRT_DEV void shadeClosestBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
 {
   const unsigned lane = lane_id();

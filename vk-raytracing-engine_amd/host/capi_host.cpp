@@ -4,6 +4,7 @@
 #include <string>
 
 #include "hello_vkrt.h"
+#include "strip_gather.h"
 
 using namespace vkrt_host;
 
@@ -137,6 +138,33 @@ int vkrt_host_write_png(const char* path, const float* displayRgba, int w, int h
     g_err = e.what();
     return 1;
   }
+}
+
+// ---- multi-GPU strip layout (strip_gather.h) for the harness: row map on the host, un-interleave kernel on the device ----
+uint32_t vkrt_host_strip_rows(uint32_t height, uint32_t stripRows, uint32_t world, uint32_t rank)
+{
+  vkrt_host::StripLayout L;
+  L.width = 1; L.height = height; L.stripRows = stripRows; L.world = world;
+  return L.rowsOf(rank);
+}
+void vkrt_host_strip_source(uint32_t height, uint32_t stripRows, uint32_t world, uint32_t y, uint32_t* rank, uint32_t* local)
+{
+  vkrt_host::StripLayout L;
+  L.width = 1; L.height = height; L.stripRows = stripRows; L.world = world;
+  L.source(y, *rank, *local);
+}
+// gathered: device [world][capRows][width] rgba32f; full: device [height][width] rgba32f
+int vkrt_host_unpack_strips(const float* gathered, float* full, uint32_t width, uint32_t height, uint32_t stripRows, uint32_t world, void* hipStream)
+{
+  vkrt_host::StripLayout L;
+  L.width = width; L.height = height; L.stripRows = stripRows; L.world = world;
+  const hipError_t e = vkrt_host::unpackStrips(gathered, full, L, (hipStream_t)hipStream);
+  if(e != hipSuccess)
+  {
+    g_err = std::string("unpackStrips: ") + hipGetErrorString(e);
+    return 1;
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -68,10 +68,19 @@ void HelloVkrt::createTopLevelAsGltf()
   check(vkrt_accel_build(m_scene, m_buildFlags, nullptr), "vkrt_accel_build");
 }
 
+void HelloVkrt::setShard(uint32_t rank, uint32_t world)
+{
+  if(world == 0 || rank >= world)
+    throw std::runtime_error("setShard: bad rank / world");
+  m_shard = vkrt_shard{0, 0, world > 1 ? 16u : 0u, world, world > 1 ? rank : 0u};
+}
+
 void HelloVkrt::createOffscreenRender()
 {
   float** planes[6] = {&m_offscreenColor, &m_positionTexture, &m_normalTexture, &m_roughnessTexture, &m_accumulatedTexture, &m_displayImage};
-  const size_t px = (size_t)m_size.width * m_size.height;
+  m_shard.full_width = (uint32_t)m_size.width;
+  m_shard.full_height = (uint32_t)m_size.height;
+  const size_t px = (size_t)m_size.width * (m_shard.shard_count > 1 ? vkrt_shard_rows(&m_shard) : (uint32_t)m_size.height);
   const size_t bytes[6] = {px * 16, px * 16, px * 16, px * 8, px * 16, px * 16};
   if(hipSetDevice(m_device) != hipSuccess)
     throw std::runtime_error("createOffscreenRender: hipSetDevice failed");
@@ -111,12 +120,16 @@ void HelloVkrt::pathtrace(const float clearColor[4])
     throw std::runtime_error("pathtrace before scene/offscreen image creation");
   for(int k = 0; k < 4; k++) m_pcRay.clearColor[k] = clearColor[k];
   const vkrt_trace_opts opts{m_seed, m_traceFlags};
-  const vkrt_shard shard{(uint32_t)m_size.width, (uint32_t)m_size.height, 0, 1, 0};
+  vkrt_shard shard = m_shard;
+  shard.full_width = (uint32_t)m_size.width;
+  shard.full_height = (uint32_t)m_size.height;
   check(vkrt_pathtrace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, m_offscreenColor, nullptr), "vkrt_pathtrace");
 }
 
 void HelloVkrt::rasterizeGltf(const float clearColor[4])
 {
+  if(m_shard.shard_count > 1)
+    throw std::runtime_error("hybrid mode is single-GPU (setShard applies to the path tracer)");
   if(!m_scene || !m_offscreenColor)
     throw std::runtime_error("rasterizeGltf before scene/offscreen image creation");
   const vkrt_shard shard{(uint32_t)m_size.width, (uint32_t)m_size.height, 0, 1, 0};

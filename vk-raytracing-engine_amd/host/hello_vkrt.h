@@ -51,6 +51,11 @@ public:
   void raytraceRasterizedScene();                         // :1450-1473
   void drawPost(std::vector<float>& displayRgba);         // :882-897 + post.frag (composite + gamma), downloaded
   void onResize(int w, int h);                            // :620-626
+  // multi-GPU (one process per GPU): this object renders only the strips of `rank` (vkrt_shard, 16-row strips dealt round-robin);
+  // call before createOffscreenRender.  Path-tracer mode only.  The strips are gathered by StripGather (strip_gather.h).
+  void setShard(uint32_t rank, uint32_t world);
+  const vkrt_shard& shard() const { return m_shard; }
+  const float* offscreenDevice() const { return m_offscreenColor; }
   void destroyResources();                                // :518-578
 
   // read back m_offscreenColor (rgba32f, row 0 = top) -- what drawPost samples (:882-897)
@@ -84,6 +89,7 @@ private:
   float* m_accumulatedTexture = nullptr;
   float* m_displayImage = nullptr;
   bool m_blasRequested = false;
+  vkrt_shard m_shard{0, 0, 0, 1, 0};  // whole image unless setShard was called
   // updateFrame()'s function-local statics in the reference (:1508-1509)
   vkrt_mat4 m_refCamMatrix{};
   float m_refFov = 60.0f;

@@ -6,28 +6,92 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <vector>
+
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <hip/hip_runtime.h>
 
 #include "hello_vkrt.h"
+#include "strip_gather.h"
 
 using namespace vkrt_host;
 
+// `--ranks N`: one child process per GPU (rank r renders on device r), started before this process touches HIP; the children
+// find each other through the RCCL id file.  Returns the worst child exit code.
+static int spawnRanks(int ranks, int argc, char** argv)
+{
+  char idFile[64];
+  snprintf(idFile, sizeof idFile, "/tmp/vkrt_rccl_id_%d", (int)getpid());
+  unlink(idFile);
+  std::vector<pid_t> kids;
+  for(int r = 0; r < ranks; r++)
+  {
+    const pid_t pid = fork();
+    if(pid == 0)
+    {
+      std::vector<std::string> keep;
+      for(int i = 0; i < argc; i++)
+      {
+        if(!strcmp(argv[i], "--ranks")) { i++; continue; }
+        keep.push_back(argv[i]);
+      }
+      keep.insert(keep.end(), {"--rank", std::to_string(r), "--world", std::to_string(ranks), "--rccl-id-file", idFile, "--device", std::to_string(r)});
+      std::vector<char*> av;
+      for(auto& k : keep) av.push_back(const_cast<char*>(k.c_str()));
+      av.push_back(nullptr);
+      execv("/proc/self/exe", av.data());
+      perror("execv");
+      _exit(127);
+    }
+    if(pid < 0) { perror("fork"); return 1; }
+    kids.push_back(pid);
+  }
+  int worst = 0;
+  for(pid_t k : kids)
+  {
+    int st = 0;
+    waitpid(k, &st, 0);
+    const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
+    worst = rc > worst ? rc : worst;
+  }
+  unlink(idFile);
+  return worst;
+}
+
 int main(int argc, char** argv)
 {
-  std::string cfgPath = "config.json", outOverride;
-  int device = 0;
+  std::string cfgPath = "config.json", outOverride, idFile;
+  int device = 0, ranks = 0, rank = 0, world = 1;
   for(int i = 1; i < argc; i++)
   {
+    if(!strcmp(argv[i], "--ranks") && i + 1 < argc) { ranks = atoi(argv[++i]); continue; }
+    if(!strcmp(argv[i], "--rank") && i + 1 < argc) { rank = atoi(argv[++i]); continue; }
+    if(!strcmp(argv[i], "--world") && i + 1 < argc) { world = atoi(argv[++i]); continue; }
+    if(!strcmp(argv[i], "--rccl-id-file") && i + 1 < argc) { idFile = argv[++i]; continue; }
     if(!strcmp(argv[i], "--config") && i + 1 < argc) cfgPath = argv[++i];
     else if(!strcmp(argv[i], "--output") && i + 1 < argc) outOverride = argv[++i];
     else if(!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
     else if(!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help"))
     {
-      printf("usage: vkrt_render [--config config.json] [--output prefix] [--device N]\n");
+      printf("usage: vkrt_render [--config config.json] [--output prefix] [--device N]\n"
+             "                   [--ranks N]                                  one process per GPU on this node, strips gathered over RCCL\n"
+             "                   [--rank R --world N --rccl-id-file PATH]     one rank of a job started by another launcher\n");
       return 0;
     }
     else cfgPath = argv[i];
   }
+  if(ranks > 0)
+    return spawnRanks(ranks, argc, argv);  // (nothing above initialises the GPU)
+  if(world < 1 || rank < 0 || rank >= world || (world > 1 && idFile.empty()))
+  {
+    fprintf(stderr, "vkrt_render: --rank/--world/--rccl-id-file inconsistent\n");
+    return 2;
+  }
+  const bool gatherMode = !idFile.empty();
   try
   {
     const AppConfig cfg = loadConfig(cfgPath);
@@ -38,6 +102,16 @@ int main(int argc, char** argv)
 
     HelloVkrt helloVk(device);
     helloVk.setup(cfg.width, cfg.height);                       // main.cpp:209-216
+    helloVk.setShard((uint32_t)rank, (uint32_t)world);
+    std::unique_ptr<StripGather> gather;
+    if(gatherMode)
+    {
+      if(cfg.mode == "hybrid")
+        throw std::runtime_error("multi-GPU strips apply to the path tracer (mode \"pathtrace\")");
+      StripLayout L;
+      L.width = (uint32_t)cfg.width; L.height = (uint32_t)cfg.height; L.stripRows = 16; L.world = (uint32_t)world;
+      gather.reset(new StripGather(L, (uint32_t)rank, device, idFile));
+    }
     if(cfg.hasCamera)
     {
       helloVk.CameraManip.setLookat(cfg.eye, cfg.center, cfg.up);
@@ -68,7 +142,11 @@ int main(int argc, char** argv)
       helloVk.updateFrame();                                    // main.cpp:504
       helloVk.m_seed = (uint32_t)cfg.seed + (cfg.seedPerFrame ? (uint32_t)f : 0u);
       if(!hybrid)
+      {
         helloVk.pathtrace(cfg.clearColor);                      // main.cpp:507
+        if(gather && f + 1 == cfg.frames)  // every rank keeps accumulating its own strips; the image is needed once, at the end
+          gather->gather(helloVk.offscreenDevice(), nullptr);
+      }
       else
       {
         helloVk.rasterizeGltf(cfg.clearColor);                  // main.cpp:513
@@ -82,7 +160,20 @@ int main(int argc, char** argv)
            cfg.width, cfg.height, cfg.samples, cfg.depth, traceMs, traceMs > 0 ? rays / traceMs / 1e3 : 0.0,
            (unsigned long long)c.rays_closest, (unsigned long long)c.rays_shadow);
     const std::string out = !outOverride.empty() ? outOverride : cfg.output;
-    if(!out.empty())
+    if(gather)
+    {
+      // rank 0 writes the gathered linear image (PFM) and its gamma preview; all ranks hold the same full image
+      if(hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
+      if(rank == 0 && !out.empty())
+      {
+        std::vector<float> img((size_t)cfg.width * cfg.height * 4);
+        if(hipMemcpy(img.data(), gather->fullImage(), img.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy failed");
+        writePFM(out + ".pfm", img, cfg.width, cfg.height);
+        writePPM(out + ".ppm", img, cfg.width, cfg.height);
+        printf("rank 0 of %d wrote %s.pfm / %s.ppm (strips gathered with one RCCL all-gather)\n", world, out.c_str(), out.c_str());
+      }
+    }
+    else if(!out.empty())
     {
       std::vector<float> img, display;
       helloVk.drawPost(display);                                // main.cpp:605-612: what the window would show

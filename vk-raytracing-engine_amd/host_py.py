@@ -36,8 +36,35 @@ def lib():
         L.vkrt_host_decode_png.restype = C.c_int
         L.vkrt_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.vkrt_host_write_png.restype = C.c_int
+        L.vkrt_host_strip_rows.argtypes = [C.c_uint32] * 4
+        L.vkrt_host_strip_rows.restype = C.c_uint32
+        L.vkrt_host_strip_source.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)] * 2
+        L.vkrt_host_unpack_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.vkrt_host_unpack_strips.restype = C.c_int
         _lib = L
     return _lib
+
+
+def strip_rows(height, world, rank, strip_rows_=16):
+    """rows of `rank`'s strip buffer in the C++ host's multi-GPU layout (host/strip_gather.h)"""
+    return int(lib().vkrt_host_strip_rows(height, strip_rows_, world, rank))
+
+
+def strip_source(height, world, y, strip_rows_=16):
+    """(rank, local row) that holds global row y"""
+    r, l = C.c_uint32(), C.c_uint32()
+    lib().vkrt_host_strip_source(height, strip_rows_, world, y, C.byref(r), C.byref(l))
+    return int(r.value), int(l.value)
+
+
+def unpack_strips(gathered, full, world, strip_rows_=16, stream=None):
+    """HIP un-interleave kernel of the C++ host: gathered [world, cap, W, 4] -> full [H, W, 4] (torch CUDA tensors)."""
+    H, W = int(full.shape[0]), int(full.shape[1])
+    rc = lib().vkrt_host_unpack_strips(C.c_void_p(gathered.data_ptr()), C.c_void_p(full.data_ptr()), W, H, strip_rows_, world,
+                                       C.c_void_p(stream.cuda_stream) if stream is not None else None)
+    if rc != 0:
+        raise RuntimeError(lib().vkrt_host_last_error().decode())
+    return full
 
 
 def load_gltf(path):
