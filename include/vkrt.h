@@ -242,6 +242,25 @@ int vkrt_gbuffer_raycast(vkrt_scene* scene, const float clearColor[4], int light
  * accum_rgba32f (eAccumMap; rgb = indirect light, a = visibility * (1 - ao)). */
 int vkrt_hybrid_trace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts,
                       const vkrt_shard* shard, const vkrt_gbuffer* gbuffer, float* accum_rgba32f_device, void* hip_stream);
+/* ---- NRD / REBLUR front-end planes ----------------------------------------------------------
+ * The raster pass also writes the denoiser's inputs (frag_shader.frag:133-136, attachments hello_vulkan.cpp:690-741) and
+ * raytraceHybrid.rgen:273-281 packs the GI radiance + normalised hit distance for REBLUR (gltf.glsl:156-273, hitDistParams
+ * (3, 1, 20, -25)).  The reference's NRD.Denoise call is commented out (main.cpp:566-602), so these planes have no consumer
+ * there; they are offered as optional outputs so a host that enables NRD finds its inputs.  All three are plain float planes
+ * holding the values the Vulkan attachments would store (rgb10_a2 UNORM / r16f / rgba16f quantisation applied). */
+typedef struct vkrt_nrd_planes {
+  float* normalRoughness;     /* rgba32f eInNormRough: oct-encoded normal .xy, roughness, clamp(materialId / 3, 0, 1); cleared to 0   */
+  float* viewZ;               /* 1 float/pixel eInViewZ: (pcRaster.viewMatrix * worldPos).z; cleared to 0                             */
+  float* diffRadianceHitDist; /* rgba32f eInRadHitD: YCoCg radiance of the GI path + normalised hit distance; 0 where GI did not run */
+} vkrt_nrd_planes;
+/* vkrt_gbuffer_raycast that also fills nrd->normalRoughness / viewZ and clears nrd->diffRadianceHitDist.
+ * view_matrix = PushConstantRaster.viewMatrix (hello_vulkan.cpp:600), column-major 4x4. */
+int vkrt_gbuffer_raycast_nrd(vkrt_scene* scene, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const float view_matrix[16],
+                             const vkrt_shard* shard, const vkrt_gbuffer* out, const vkrt_nrd_planes* nrd, void* hip_stream);
+/* vkrt_hybrid_trace that also writes nrd->diffRadianceHitDist where PushConstantRay.useGI ran (reads nrd->viewZ). */
+int vkrt_hybrid_trace_nrd(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts,
+                          const vkrt_shard* shard, const vkrt_gbuffer* gbuffer, const vkrt_nrd_planes* nrd, float* accum_rgba32f_device,
+                          void* hip_stream);
 /* Replaces drawPost's fragment stage (post.frag:36-58): hybrid composite main.rgb * rt.a + rt.rgb (rtMode 0) or
  * pass-through (rtMode 1), then gamma 1/2.2 on all four channels.  n_pixels rgba32f device buffers. */
 int vkrt_post(int device, const PushConstantPost* pc, uint32_t n_pixels, const float* main_rgba32f, const float* rt_rgba32f,

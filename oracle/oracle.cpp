@@ -1047,12 +1047,45 @@ inline float quantizeHalf(float f)
 struct GbufPixel
 {
   float color[4], position[4], normal[4], rough[2];
+  float nrdNormRough[4], nrdViewZ;  // NRD front-end planes of the raster pass (frag_shader.frag:133-136); filled when viewMatrix != NULL
 };
+
+// ---- NRD / REBLUR front-end packing (gltf.glsl:156-273), written out with the profile's operation order -----------------
+inline float stepf(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+// gltf.glsl:157-165 _NRD_EncodeUnitVector(v, false)
+inline void nrdEncodeUnitVector(V3 v, float out[2])
+{
+  const float n = (std::fabs(v.x) * 1.0f + std::fabs(v.y) * 1.0f) + std::fabs(v.z) * 1.0f;  // dot(abs(v), vec3(1))
+  v = v / n;
+  const float wx = (1.0f - std::fabs(v.y)) * (stepf(0.0f, v.x) * 2.0f - 1.0f);
+  const float wy = (1.0f - std::fabs(v.x)) * (stepf(0.0f, v.y) * 2.0f - 1.0f);
+  const float ex = v.z >= 0.0f ? v.x : wx, ey = v.z >= 0.0f ? v.y : wy;
+  out[0] = ex * 0.5f + 0.5f;
+  out[1] = ey * 0.5f + 0.5f;
+}
+// UNORM store of an rgb10_a2 attachment (hello_vulkan.cpp:690-741 eInNormRough): round to nearest even step
+inline float quantizeUnorm(float x, float levels)
+{
+  const float c = glsl_clamp(x, 0.0f, 1.0f);
+  return std::nearbyintf(c * levels) / levels;
+}
+// gltf.glsl:167-177 NRD_FrontEnd_PackNormalAndRoughness + the rgb10_a2 store
+inline void nrdPackNormalRoughness(V3 N, float roughness, float materialID, float out[4])
+{
+  float e[2];
+  nrdEncodeUnitVector(N, e);
+  out[0] = quantizeUnorm(e[0], 1023.0f);
+  out[1] = quantizeUnorm(e[1], 1023.0f);
+  out[2] = quantizeUnorm(roughness, 1023.0f);
+  out[3] = quantizeUnorm(glsl_clamp(materialID / 3.0f, 0.0f, 1.0f), 3.0f);
+}
 
 // vert_shader.vert:60-74 per vertex, barycentric interpolation (what the rasteriser does), frag_shader.frag:122-214
 void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount, const GlobalUniforms& uni, uint32_t x, uint32_t y, uint32_t W,
-                  uint32_t H, bool useBvh, GbufPixel& out, Counters& c)
+                  uint32_t H, bool useBvh, GbufPixel& out, Counters& c, const float* viewMatrix = nullptr)
 {
+  out.nrdNormRough[0] = out.nrdNormRough[1] = out.nrdNormRough[2] = out.nrdNormRough[3] = 0.0f;  // main.cpp:488-491 clear values
+  out.nrdViewZ = 0.0f;
   ShadeCtx cx{s, c};
   for(int k = 0; k < 4; k++) out.color[k] = clearColor[k];            // main.cpp:483
   out.position[0] = out.position[1] = out.position[2] = 0.0f; out.position[3] = 1.0f;   // main.cpp:485
@@ -1147,11 +1180,21 @@ void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount
   out.normal[0] = N.x; out.normal[1] = N.y; out.normal[2] = N.z; out.normal[3] = albedo.z;
   out.rough[0] = quantizeHalf(roughness);
   out.rough[1] = quantizeHalf(metalness);
+  if(viewMatrix)
+  {  // frag_shader.frag:134-135: NRD normal / roughness / material plane (rgb10_a2) and view-space depth (r16f)
+    nrdPackNormalRoughness(N, roughness, (float)pm.materialIndex, out.nrdNormRough);
+    const float w4[4] = {wPos.x, wPos.y, wPos.z, 1.0f};
+    float vz[4];
+    vkrt_mat4 VM;
+    memcpy(VM.m, viewMatrix, sizeof VM.m);
+    mat4MulVec4(VM, w4, vz);
+    out.nrdViewZ = quantizeHalf(vz[2]);
+  }
 }
 
 // raytraceHybrid.rgen:50-303 for one pixel; accum = imageAccum texel (in/out)
 void hybridPixel(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms& uni, uint32_t seedArg, uint32_t flags, uint32_t x, uint32_t y,
-                 uint32_t W, bool useBvh, const GbufPixel& g, float* accum, Counters& c)
+                 uint32_t W, bool useBvh, const GbufPixel& g, float* accum, Counters& c, float* nrdRadHitD = nullptr)
 {
   ShadeCtx cx{s, c};
   c.pixels++;
@@ -1211,9 +1254,10 @@ void hybridPixel(const orc_scene& s, const PushConstantRay& pc, const GlobalUnif
     }
     color[3] *= (1.0f - ao);
   }
-  if(pc.useGI == 1)  // rgen:172-282 (the NRD packing at :273-281 is inert and not restated)
+  if(pc.useGI == 1)  // rgen:172-282
   {
     V3 hitValues = v3(0.0f);
+    float hitDists = 0.0f;
     const float tMin = 0.001f, tMax = 10000.0f;
     V3 direction, curWeight;
     const float ratio = metalness * (1.0f - roughness);
@@ -1258,10 +1302,29 @@ void hybridPixel(const orc_scene& s, const PushConstantRay& pc, const GlobalUnif
         const V3 q = prd.hitValue * curWeight;
         hitValue = hitValue + v3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
       }
+      if(prd.depth == 1 && !prd.isSpecular)  // rgen:253-264
+        hitDists = shadowHit ? 0.5f * prd.lightDist : prd.lightDist;
       curWeight = curWeight * prd.weight;
     }
     hitValues = hitValues + hitValue;
     color[0] = hitValues.x; color[1] = hitValues.y; color[2] = hitValues.z;
+    if(nrdRadHitD)
+    {  // rgen:273-281: REBLUR front end with hitDistParams (3, 1, 20, -25); o_diffRadianceHitD is rgba16f
+      const float viewZ = g.nrdViewZ;
+      const float t = glsl_clamp(exp2f(-25.0f * roughness * roughness), 0.0f, 1.0f);
+      const float f = (3.0f + std::fabs(viewZ) * 1.0f) * (1.0f * (1.0f - t) + 20.0f * t);  // gltf.glsl:253-257
+      float normHitDist = glsl_clamp(hitDists / f, 0.0f, 1.0f);                          // :259-264
+      V3 rad = hitValues;                                                               // :219-238 with sanitize = true
+      const bool bad = std::isnan(rad.x) || std::isnan(rad.y) || std::isnan(rad.z) || std::isinf(rad.x) || std::isinf(rad.y) || std::isinf(rad.z);
+      rad = bad ? v3(0.0f) : v3(glsl_clamp(rad.x, 0.0f, 65504.0f), glsl_clamp(rad.y, 0.0f, 65504.0f), glsl_clamp(rad.z, 0.0f, 65504.0f));
+      normHitDist = (std::isnan(normHitDist) || std::isinf(normHitDist)) ? 0.0f : glsl_clamp(normHitDist, 0.0f, 1.0f);
+      if(normHitDist != 0.0f)
+        normHitDist = glsl_max(normHitDist, 1e-7f);
+      const float Y = (rad.x * 0.25f + rad.y * 0.5f) + rad.z * 0.25f;                   // :206-213 _NRD_LinearToYCoCg
+      const float Co = (rad.x * 0.5f + rad.y * 0.0f) + rad.z * -0.5f;
+      const float Cg = (rad.x * -0.25f + rad.y * 0.5f) + rad.z * -0.25f;
+      nrdRadHitD[0] = quantizeHalf(Y); nrdRadHitD[1] = quantizeHalf(Co); nrdRadHitD[2] = quantizeHalf(Cg); nrdRadHitD[3] = quantizeHalf(normHitDist);
+    }
   }
   accumulateFrames();
 }
@@ -1586,6 +1649,56 @@ int orc_gbuffer_rows(const orc_scene* s, const float* clearColor, int lightsCoun
   for(int t = 1; t < nt; t++) th.emplace_back(work);
   work();
   for(auto& t : th) t.join();
+  return 0;
+}
+
+/* The same raster-pass stand-in with the three NRD front-end attachments (frag_shader.frag:133-136): normRough (rgb10_a2 values),
+ * viewZ (r16f values); viewMatrix = pcRaster.viewMatrix, column-major. */
+int orc_gbuffer_rows_nrd(const orc_scene* s, const float* clearColor, int lightsCount, const GlobalUniforms* cam, const float* viewMatrix,
+                         uint32_t full_w, uint32_t full_h, const uint32_t* rows, uint32_t nrows, float* color, float* position, float* normal,
+                         float* rough, float* normRough, float* viewZ, int use_bvh)
+{
+  if(lightsCount < 0 || (uint32_t)lightsCount > s->lights.size())
+  {
+    snprintf(g_err, sizeof g_err, "lightsCount out of range");
+    return 1;
+  }
+  Counters c;
+  for(uint32_t r = 0; r < nrows; r++)
+    for(uint32_t x = 0; x < full_w; x++)
+    {
+      GbufPixel g;
+      gbufferPixel(*s, clearColor, lightsCount, *cam, x, rows[r], full_w, full_h, use_bvh != 0, g, c, viewMatrix);
+      const size_t p = (size_t)r * full_w + x;
+      memcpy(color + 4 * p, g.color, 16); memcpy(position + 4 * p, g.position, 16); memcpy(normal + 4 * p, g.normal, 16);
+      memcpy(rough + 2 * p, g.rough, 8); memcpy(normRough + 4 * p, g.nrdNormRough, 16);
+      viewZ[p] = g.nrdViewZ;
+    }
+  return 0;
+}
+
+/* raytraceHybrid.rgen incl. its REBLUR front end (rgen:273-281): viewZ in, radHitD (rgba16f values) out (written where GI ran). */
+int orc_hybrid_rows_nrd(const orc_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, uint32_t seed, uint32_t flags, uint32_t full_w,
+                        uint32_t full_h, const uint32_t* rows, uint32_t nrows, const float* color, const float* position, const float* normal,
+                        const float* rough, const float* viewZ, float* accum, float* radHitD, int use_bvh)
+{
+  (void)full_h;
+  if(pc->lightsCount < 0 || (uint32_t)pc->lightsCount > s->lights.size())
+  {
+    snprintf(g_err, sizeof g_err, "lightsCount out of range");
+    return 1;
+  }
+  Counters c;
+  for(uint32_t r = 0; r < nrows; r++)
+    for(uint32_t x = 0; x < full_w; x++)
+    {
+      const size_t p = (size_t)r * full_w + x;
+      GbufPixel g;
+      memcpy(g.color, color + 4 * p, 16); memcpy(g.position, position + 4 * p, 16); memcpy(g.normal, normal + 4 * p, 16);
+      memcpy(g.rough, rough + 2 * p, 8);
+      g.nrdViewZ = viewZ[p];
+      hybridPixel(*s, *pc, *cam, seed, flags, x, rows[r], full_w, use_bvh != 0, g, accum + 4 * p, c, radHitD + 4 * p);
+    }
   return 0;
 }
 

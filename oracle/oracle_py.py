@@ -56,6 +56,12 @@ def lib():
         L.orc_hybrid_rows.argtypes = [C.c_void_p, P(abi.PushConstantRay), P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_hybrid_rows.restype = C.c_int
+        L.orc_gbuffer_rows_nrd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(abi.GlobalUniforms), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_gbuffer_rows_nrd.restype = C.c_int
+        L.orc_hybrid_rows_nrd.argtypes = [C.c_void_p, P(abi.PushConstantRay), P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_hybrid_rows_nrd.restype = C.c_int
         L.orc_post.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_quantize_half.argtypes = [C.c_float]
         L.orc_quantize_half.restype = C.c_float
@@ -158,6 +164,36 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("orc_hybrid_rows: " + lib().orc_last_error().decode())
         return accum, dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
+
+    def gbuffer_nrd(self, cam, view_matrix, width, height, lights_count, clear_color=(1.0, 1.0, 1.0, 1.0), rows=None, use_bvh=True):
+        """gbuffer() plus the NRD front-end planes of the raster pass (frag_shader.frag:133-136)."""
+        rows = np.arange(height, dtype=np.uint32) if rows is None else np.ascontiguousarray(rows, np.uint32)
+        n = rows.shape[0]
+        g = {"color": np.zeros((n, width, 4), np.float32), "position": np.zeros((n, width, 4), np.float32),
+             "normal": np.zeros((n, width, 4), np.float32), "roughMetal": np.zeros((n, width, 2), np.float32),
+             "nrdNormalRoughness": np.zeros((n, width, 4), np.float32), "nrdViewZ": np.zeros((n, width), np.float32)}
+        cc = np.asarray(clear_color, np.float32)
+        vm = np.ascontiguousarray(view_matrix, np.float32).reshape(16)
+        rc = lib().orc_gbuffer_rows_nrd(self._h, cc.ctypes.data, lights_count, C.byref(cam), vm.ctypes.data, width, height, rows.ctypes.data, n,
+                                        g["color"].ctypes.data, g["position"].ctypes.data, g["normal"].ctypes.data, g["roughMetal"].ctypes.data,
+                                        g["nrdNormalRoughness"].ctypes.data, g["nrdViewZ"].ctypes.data, 1 if use_bvh else 0)
+        if rc != 0:
+            raise RuntimeError("orc_gbuffer_rows_nrd: " + lib().orc_last_error().decode())
+        return g
+
+    def hybrid_nrd(self, pc, cam, width, height, g, seed=0, flags=0, rows=None, accum=None, use_bvh=True):
+        """hybrid() plus the REBLUR input plane (raytraceHybrid.rgen:273-281); returns (accum, radianceHitDist)."""
+        rows = np.arange(height, dtype=np.uint32) if rows is None else np.ascontiguousarray(rows, np.uint32)
+        n = rows.shape[0]
+        if accum is None:
+            accum = np.zeros((n, width, 4), np.float32)
+        rad = np.zeros((n, width, 4), np.float32)
+        rc = lib().orc_hybrid_rows_nrd(self._h, C.byref(pc), C.byref(cam), seed, flags, width, height, rows.ctypes.data, n, g["color"].ctypes.data,
+                                       g["position"].ctypes.data, g["normal"].ctypes.data, g["roughMetal"].ctypes.data, g["nrdViewZ"].ctypes.data,
+                                       accum.ctypes.data, rad.ctypes.data, 1 if use_bvh else 0)
+        if rc != 0:
+            raise RuntimeError("orc_hybrid_rows_nrd: " + lib().orc_last_error().decode())
+        return accum, rad
 
     def sample_texture(self, tex_index, uv):
         uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)

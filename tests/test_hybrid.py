@@ -147,3 +147,103 @@ def test_gpu_hybrid_textured_atrium_and_toggles():
         ref, _ = orc.hybrid(pc, cam, W, H, gnp, seed=5)
         assert _mismatch(out, ref) < 2e-4, (sh, ao, gi)
     r.close()
+
+
+# ---- NRD / REBLUR front-end planes (gltf.glsl:156-273) -------------------------------------------------
+@pytest.fixture(scope="module")
+def small_scene():
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import atrium
+
+    flat, _ = atrium.build_atrium(6000, seed=3, with_textures=True, variant="emissive_mixed_lights")
+    return flat, atrium.DEFAULT_CAMERA
+
+
+def _view_matrix(camkw):
+    import camera_np
+
+    V = camera_np.look_at(camkw.get("eye", (0, 0, 15)), camkw.get("center", (0, 0, 0)), camkw.get("up", (0, 1, 0)))
+    return np.asarray(V, np.float32).T.reshape(-1).copy()  # column-major
+
+
+def _decode_oct(p):
+    """_NRD_DecodeUnitVector(p, false, true), gltf.glsl:179-190"""
+    q = p * 2.0 - 1.0
+    n = np.stack([q[..., 0], q[..., 1], 1.0 - np.abs(q[..., 0]) - np.abs(q[..., 1])], -1)
+    t = np.clip(-n[..., 2], 0.0, 1.0)
+    n[..., 0] -= t * np.where(n[..., 0] >= 0, 1.0, -1.0)
+    n[..., 1] -= t * np.where(n[..., 1] >= 0, 1.0, -1.0)
+    return n / np.linalg.norm(n, axis=-1, keepdims=True)
+
+
+def test_oracle_nrd_planes_decode_back_to_the_gbuffer(small_scene):
+    """Property test of the packing on the CPU oracle: the oct-encoded normal decodes to the G-buffer normal within the
+    rgb10 quantisation, roughness / viewZ match their sources, the packed radiance unpacks (YCoCg -> linear) to the GI term."""
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+
+    flat, camkw = small_scene
+    W, H = 160, 90
+    cam = default_camera(W, H, **camkw)
+    orc = oracle_py.OracleScene(flat)
+    L = len(flat.lights)
+    g = orc.gbuffer_nrd(cam, _view_matrix(camkw), W, H, lights_count=L)
+    g0 = orc.gbuffer(cam, W, H, lights_count=L)
+    for k in g0:
+        assert np.array_equal(g[k].view(np.uint32), g0[k].view(np.uint32)), k
+    hit = np.any(g["position"][..., :3] != 0, axis=-1)
+    assert 0.5 < hit.mean() <= 1.0
+    n = _decode_oct(g["nrdNormalRoughness"][..., :2].astype(np.float64))
+    assert np.abs(n[hit] - g["normal"][..., :3][hit]).max() < 4e-3  # 10-bit oct encoding
+    assert np.abs(g["nrdNormalRoughness"][..., 2][hit] - g["roughMetal"][..., 0][hit]).max() <= 0.5 / 1023 + 1e-3
+    assert np.all(g["nrdNormalRoughness"][~hit] == 0) and np.all(g["nrdViewZ"][~hit] == 0)
+    eye = np.asarray(camkw.get("eye", (0, 0, 15)), np.float64)
+    fwd = np.asarray(camkw.get("center", (0, 0, 0)), np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    depth = -((g["position"][..., :3].astype(np.float64) - eye) @ fwd)  # right-handed view space looks down -z
+    assert np.abs(g["nrdViewZ"][hit] - depth[hit]).max() < 0.02 * np.abs(depth[hit]).max()  # r16f
+    pc = make_push_constants(samples=1, depth=5, frame=0, lights_count=L)
+    pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+    acc, rad = orc.hybrid_nrd(pc, cam, W, H, g, seed=9)
+    acc0, _ = orc.hybrid(pc, cam, W, H, g0, seed=9)
+    assert np.array_equal(acc.view(np.uint32), acc0.view(np.uint32))
+    Y, Co, Cg = rad[..., 0].astype(np.float64), rad[..., 1].astype(np.float64), rad[..., 2].astype(np.float64)
+    t = Y - Cg
+    lin = np.maximum(np.stack([t + Co, Y + Cg, t - Co], -1), 0.0)  # _NRD_YCoCgToLinear, gltf.glsl:215-225
+    want = np.clip(acc[..., :3].astype(np.float64), 0, 65504.0)
+    assert np.abs(lin[hit] - want[hit]).max() <= 2e-3 * max(1.0, want[hit].max())  # three half-precision stores
+    assert np.all((rad[..., 3] >= 0) & (rad[..., 3] <= 1)) and (rad[..., 3][hit] > 0).mean() > 0.3 and np.all(rad[~hit] == 0)
+
+
+@pytest.mark.gpu
+def test_gpu_nrd_planes_match_oracle(small_scene):
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat, camkw = small_scene
+    W, H = 256, 144
+    cam = default_camera(W, H, **camkw)
+    vm = _view_matrix(camkw)
+    L = len(flat.lights)
+    orc = oracle_py.OracleScene(flat)
+    r = Renderer(flat, device=0, build="sah")
+    g = r.gbuffer_raycast(cam, W, H, lights_count=L, view_matrix=vm)
+    go = orc.gbuffer_nrd(cam, vm, W, H, lights_count=L)
+    for k in ("nrdNormalRoughness", "nrdViewZ"):
+        got = g[k].cpu().numpy()
+        assert np.mean(got.view(np.uint32) != go[k].view(np.uint32)) < 2e-3, k   # same arithmetic; a rare quantisation-boundary flip
+        assert np.abs(got - go[k]).max() <= (1.5 / 1023 if k == "nrdNormalRoughness" else 0.05)
+    pc = make_push_constants(samples=1, depth=5, frame=0, lights_count=L)
+    pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+    acc = r.hybrid_trace(pc, cam, W, H, g, seed=9)
+    gnp = {k: v.cpu().numpy() for k, v in g.items()}
+    acc_o, rad_o = orc.hybrid_nrd(pc, cam, W, H, gnp, seed=9)
+    rad = g["nrdRadianceHitDist"].cpu().numpy()
+    r.close()
+    assert np.mean(np.any(acc.cpu().numpy().view(np.uint32) != acc_o.view(np.uint32), axis=-1)) < 1e-3
+    assert np.mean(np.any(rad.view(np.uint32) != rad_o.view(np.uint32), axis=-1)) < 5e-3   # exp2f differs in the last bits between CPU and GPU
+    assert np.abs(rad - rad_o).max() < 5e-3 * max(1.0, np.abs(rad_o).max())

@@ -146,6 +146,10 @@ class Gbuffer(C.Structure):
     _fields_ = [("color", C.c_void_p), ("position", C.c_void_p), ("normal", C.c_void_p), ("roughMetal", C.c_void_p)]
 
 
+class NrdPlanes(C.Structure):
+    _fields_ = [("normalRoughness", C.c_void_p), ("viewZ", C.c_void_p), ("diffRadianceHitDist", C.c_void_p)]
+
+
 class PushConstantPost(C.Structure):
     _fields_ = [("aspectRatio", c_f), ("rtMode", c_i), ("viewAccumulated", c_i), ("useGI", c_i)]
 
@@ -189,6 +193,8 @@ VKRT_SYMBOLS = [
     "vkrt_pathtrace",
     "vkrt_gbuffer_raycast",
     "vkrt_hybrid_trace",
+    "vkrt_gbuffer_raycast_nrd",
+    "vkrt_hybrid_trace_nrd",
     "vkrt_post",
     "vkrt_counters_reset",
     "vkrt_counters_read",
@@ -229,6 +235,11 @@ def declare_vkrt(lib):
     lib.vkrt_gbuffer_raycast.restype = C.c_int
     lib.vkrt_hybrid_trace.argtypes = [C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), P(Gbuffer), C.c_void_p, C.c_void_p]
     lib.vkrt_hybrid_trace.restype = C.c_int
+    lib.vkrt_gbuffer_raycast_nrd.argtypes = [C.c_void_p, P(c_f * 4), C.c_int, P(GlobalUniforms), P(c_f * 16), P(Shard), P(Gbuffer), P(NrdPlanes), C.c_void_p]
+    lib.vkrt_gbuffer_raycast_nrd.restype = C.c_int
+    lib.vkrt_hybrid_trace_nrd.argtypes = [C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), P(Gbuffer), P(NrdPlanes), C.c_void_p,
+                                          C.c_void_p]
+    lib.vkrt_hybrid_trace_nrd.restype = C.c_int
     lib.vkrt_post.argtypes = [C.c_int, P(PushConstantPost), c_u, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vkrt_post.restype = C.c_int
     lib.vkrt_counters_reset.argtypes = [C.c_void_p, C.c_void_p]

@@ -62,7 +62,26 @@ struct HybridParams
   float4* accum;      // eAccumMap  rgba32f
   float clearColor[4];
   int lightsCount;
+  // optional NRD / REBLUR front-end attachments (frag_shader.frag:133-136, raytraceHybrid.rgen:273-281); NULL = not requested
+  float4* nrdNormRough;  // eInNormRough rgb10_a2 values
+  float* nrdViewZ;       // eInViewZ     r16f values
+  float4* nrdRadHitD;    // eInRadHitD   rgba16f values
+  float viewMatrix[16];  // pcRaster.viewMatrix (column-major), for viewZ
 };
+
+// ---- NRD / REBLUR front-end packing, gltf.glsl:156-273 (same operation order as the oracle) -----------------------------
+VKRT_DEV float stepf(float edge, float x) { return x < edge ? 0.0f : 1.0f; }
+VKRT_DEV float quantizeUnorm(float x, float levels) { return rintf(glsl_clamp(x, 0.0f, 1.0f) * levels) / levels; }  // rgb10_a2 store
+VKRT_DEV float4 nrdPackNormalRoughness(f3 N, float roughness, float materialID)  // gltf.glsl:157-177
+{
+  const float n = (fabsf(N.x) * 1.0f + fabsf(N.y) * 1.0f) + fabsf(N.z) * 1.0f;
+  const f3 v = N / n;
+  const float wx = (1.0f - fabsf(v.y)) * (stepf(0.0f, v.x) * 2.0f - 1.0f);
+  const float wy = (1.0f - fabsf(v.x)) * (stepf(0.0f, v.y) * 2.0f - 1.0f);
+  const float ex = v.z >= 0.0f ? v.x : wx, ey = v.z >= 0.0f ? v.y : wy;
+  return make_float4(quantizeUnorm(ex * 0.5f + 0.5f, 1023.0f), quantizeUnorm(ey * 0.5f + 0.5f, 1023.0f), quantizeUnorm(roughness, 1023.0f),
+                     quantizeUnorm(glsl_clamp(materialID / 3.0f, 0.0f, 1.0f), 3.0f));
+}
 
 VKRT_DEV bool pixelOf(const TraceParams& P, uint32_t& x, uint32_t& y, uint32_t& lrow)
 {
@@ -97,6 +116,8 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
     float4 oColor = make_float4(H.clearColor[0], H.clearColor[1], H.clearColor[2], H.clearColor[3]);
     float4 oPos = make_float4(0.0f, 0.0f, 0.0f, 1.0f), oNrm = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     float2 oRough = make_float2(0.0f, 0.0f);
+    float4 oNormRough = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // main.cpp:488-491 clear values
+    float oViewZ = 0.0f;
     float origin[4], target[4], direction[4];
     mat4MulVec4(P.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f, origin);
     const float inU = ((float)x + 0.5f) / (float)P.fullW, inV = ((float)y + 0.5f) / (float)P.fullH;
@@ -192,8 +213,21 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
       oPos = make_float4(wPos.x, wPos.y, wPos.z, albedo.y);
       oNrm = make_float4(N.x, N.y, N.z, albedo.z);
       oRough = make_float2(quantizeHalf(roughness), quantizeHalf(metalness));
+      if(H.nrdNormRough)
+      {
+        oNormRough = nrdPackNormalRoughness(N, roughness, (float)ts.w);  // (materialId -1 and 0 pack alike: clamp(id / 3, 0, 1))
+        float vz[4];
+        mat4MulVec4(H.viewMatrix, wPos.x, wPos.y, wPos.z, 1.0f, vz);
+        oViewZ = quantizeHalf(vz[2]);
+      }
     }
     H.color[p] = oColor; H.position[p] = oPos; H.normal[p] = oNrm; H.rough[p] = oRough;
+    if(H.nrdNormRough)
+    {
+      H.nrdNormRough[p] = oNormRough;
+      H.nrdViewZ[p] = oViewZ;
+      H.nrdRadHitD[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // frag_shader.frag:136 / clear value
+    }
   }
   __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (HY_BLOCK / 64)];
   const unsigned vals[5] = {nClosest, 0, 0, 0, st.taps};
@@ -295,6 +329,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
         prd.depth = 1;
         prd.weight = mk3(0.0f);
         f3 hitValue = mk3(0.0f);
+        float hitDists = 0.0f;
         for(; prd.depth < (uint32_t)P.pc.depth; prd.depth++)
         {
           nClosest++;
@@ -317,9 +352,28 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
             const f3 q = prd.hitValue * curWeight;
             hitValue = hitValue + mk3(glsl_min(q.x, 10.0f), glsl_min(q.y, 10.0f), glsl_min(q.z, 10.0f));
           }
+          if(prd.depth == 1u && !prd.isSpecular)  // rgen:253-264
+            hitDists = shadowHit ? 0.5f * prd.lightDist : prd.lightDist;
           curWeight = curWeight * prd.weight;
         }
         color.x = hitValue.x; color.y = hitValue.y; color.z = hitValue.z;
+        if(H.nrdRadHitD)
+        {  // rgen:273-281: REBLUR front end, hitDistParams (3, 1, 20, -25), rgba16f store
+          const float viewZ = H.nrdViewZ[p];
+          const float t = glsl_clamp(exp2f(-25.0f * roughness * roughness), 0.0f, 1.0f);
+          const float f = (3.0f + fabsf(viewZ) * 1.0f) * (1.0f * (1.0f - t) + 20.0f * t);
+          float normHitDist = glsl_clamp(hitDists / f, 0.0f, 1.0f);
+          f3 rad = hitValue;
+          const bool bad = isnan(rad.x) || isnan(rad.y) || isnan(rad.z) || isinf(rad.x) || isinf(rad.y) || isinf(rad.z);
+          rad = bad ? mk3(0.0f) : mk3(glsl_clamp(rad.x, 0.0f, 65504.0f), glsl_clamp(rad.y, 0.0f, 65504.0f), glsl_clamp(rad.z, 0.0f, 65504.0f));
+          normHitDist = (isnan(normHitDist) || isinf(normHitDist)) ? 0.0f : glsl_clamp(normHitDist, 0.0f, 1.0f);
+          if(normHitDist != 0.0f)
+            normHitDist = glsl_max(normHitDist, 1e-7f);
+          const float Y = (rad.x * 0.25f + rad.y * 0.5f) + rad.z * 0.25f;
+          const float Co = (rad.x * 0.5f + rad.y * 0.0f) + rad.z * -0.5f;
+          const float Cg = (rad.x * -0.25f + rad.y * 0.5f) + rad.z * -0.25f;
+          H.nrdRadHitD[p] = make_float4(quantizeHalf(Y), quantizeHalf(Co), quantizeHalf(Cg), quantizeHalf(normHitDist));
+        }
       }
     }
     // accumulateFrames, rgen:36-48 (all four channels)
@@ -364,10 +418,14 @@ __global__ void k_post(int rtMode, int viewAccumulated, int useGI, unsigned n, c
 }
 
 hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], int lightsCount, float* color, float* position, float* normal,
-                               float* rough, hipStream_t stream)
+                               float* rough, const NrdPlanes* nrd, hipStream_t stream)
 {
   HybridParams H;
   H.T = P;
+  H.nrdNormRough = nrd ? (float4*)nrd->normRough : nullptr;
+  H.nrdViewZ = nrd ? nrd->viewZ : nullptr;
+  H.nrdRadHitD = nrd ? (float4*)nrd->radHitD : nullptr;
+  for(int k = 0; k < 16; k++) H.viewMatrix[k] = nrd ? nrd->viewMatrix[k] : 0.0f;
   H.color = (float4*)color; H.position = (float4*)position; H.normal = (float4*)normal; H.rough = (float2*)rough; H.accum = nullptr;
   for(int k = 0; k < 4; k++) H.clearColor[k] = clearColor[k];
   H.lightsCount = lightsCount;
@@ -381,10 +439,14 @@ hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], 
 }
 
 hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const float* position, const float* normal, const float* rough, float* accum,
-                              hipStream_t stream)
+                              const NrdPlanes* nrd, hipStream_t stream)
 {
   HybridParams H;
   H.T = P;
+  H.nrdNormRough = nullptr;
+  H.nrdViewZ = nrd ? nrd->viewZ : nullptr;
+  H.nrdRadHitD = nrd ? (float4*)nrd->radHitD : nullptr;
+  for(int k = 0; k < 16; k++) H.viewMatrix[k] = 0.0f;
   H.color = (float4*)color; H.position = (float4*)position; H.normal = (float4*)normal; H.rough = (float2*)rough; H.accum = (float4*)accum;
   for(int k = 0; k < 4; k++) H.clearColor[k] = 0.0f;
   H.lightsCount = P.pc.lightsCount;

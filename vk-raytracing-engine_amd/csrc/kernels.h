@@ -38,9 +38,16 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const
                                  const WfAsync* async);
 
 // hybrid mode (hybrid.hip)
+struct NrdPlanes  // optional NRD front-end attachments (include/vkrt.h vkrt_nrd_planes) + the raster pass's view matrix
+{
+  float* normRough;
+  float* viewZ;
+  float* radHitD;
+  float viewMatrix[16];
+};
 hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], int lightsCount, float* color, float* position, float* normal,
-                               float* rough, hipStream_t stream);
+                               float* rough, const NrdPlanes* nrd, hipStream_t stream);
 hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const float* position, const float* normal, const float* rough, float* accum,
-                              hipStream_t stream);
+                              const NrdPlanes* nrd, hipStream_t stream);
 hipError_t vkrt_launch_post(int rtMode, int viewAccumulated, int useGI, unsigned n, const float* mainImg, const float* rtImg, float* out,
                             hipStream_t stream);

@@ -9,6 +9,27 @@
 
 namespace vkrt {
 
+// Device-side collapse of the binary tree into the 8-wide compressed layout (wide_collapse.hip).
+struct WideCollapseIn
+{
+  uint32_t triCount;
+  const float4* nodes2;        // BVH2 nodes, one triangle per leaf (k_emit with leaf size 1): node i = radix-tree node i
+  const int* parentInternal;   // radix-tree parents (k_hierarchy)
+  const int* parentLeaf;
+  const float4* tris;          // 48-B records in sorted (leaf) order
+  const uint4* triShade;       // 16-B shading records in the same order
+};
+struct WideCollapseOut
+{
+  void* nodes = nullptr;       // device, 80 B per wide node, breadth-first (caller frees with hipFree)
+  void* tris = nullptr;        // device, 48 B per triangle in wide-tree order
+  void* triShade = nullptr;    // device, 16 B per triangle in the same order
+  uint32_t nodeCount = 0, maxDepth = 0;
+  float sahCost = 0;
+  bool overflow = false;       // tree deeper than the level budget: results unusable, collapse on the host instead
+};
+int collapse_wide8_device(const WideCollapseIn& in, hipStream_t stream, WideCollapseOut& out, std::string& err);
+
 struct LbvhResult
 {
   void* nodes = nullptr;  // device, 64 B per node (caller frees with hipFree)
@@ -18,10 +39,13 @@ struct LbvhResult
   int32_t rootRef = (int32_t)0x80000000;
   float sahCost = 0;
   std::string error;
+  // filled when the caller asked for the wide layout (leafSize 1, wantWide): the binary arrays above stay valid as well
+  WideCollapseOut wide;
+  bool hasWide = false;
 };
 
 // sc must already hold the uploaded positions / indices / instances.
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4);
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4, bool wantWide = false);
 
 }  // namespace vkrt

@@ -366,7 +366,7 @@ struct Temp
   } while(0)
 
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize)
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide)
 {
   const unsigned kLeaf = leafSize < 1u ? 1u : (leafSize > 8u ? 8u : leafSize);
   out = LbvhResult{};
@@ -465,6 +465,25 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
   hipLaunchKernelGGL(k_depth, dim3(G), dim3(B), 0, stream, kLeaf, (int)T, (const int2*)range, (const int*)parentInternal, (const int*)parentLeaf,
                      &scalars[0]);
   LB_TRY(hipGetLastError());
+  if(wantWide && kLeaf == 1u)
+  {
+    // the whole acceleration structure on the device: collapse the radix tree into 8-wide compressed nodes while the parent
+    // arrays are still here (wide_collapse.hip); a tree that does not fit its level budget is reported, not guessed at
+    WideCollapseIn in{T, (const float4*)out.nodes, (const int*)parentInternal, (const int*)parentLeaf, (const float4*)out.tris, (const uint4*)out.triShade};
+    const int rcw = collapse_wide8_device(in, stream, out.wide, out.error);
+    if(rcw != VKRT_OK)
+    {
+      (void)hipFree(out.nodes); (void)hipFree(out.tris); (void)hipFree(out.triShade);
+      out.nodes = out.tris = out.triShade = nullptr;
+      return rcw;
+    }
+    out.hasWide = !out.wide.overflow;
+    if(out.wide.overflow)
+    {
+      (void)hipFree(out.wide.nodes); (void)hipFree(out.wide.tris); (void)hipFree(out.wide.triShade);
+      out.wide.nodes = out.wide.tris = out.wide.triShade = nullptr;
+    }
+  }
   unsigned hs[4];
   float rootBox[6];
   LB_TRY(hipMemcpyAsync(hs, scalars, 16, hipMemcpyDeviceToHost, stream));

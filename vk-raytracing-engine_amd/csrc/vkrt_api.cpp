@@ -530,15 +530,34 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     vkrt::LbvhResult r;
     // GPU radix-tree build (Morton codes, sort, Karras hierarchy, bottom-up fit).  For the trace-optimised layout the
     // binary tree keeps one triangle per leaf and is collapsed into wide8 nodes by the same SAH-optimal DP as the SAH
-    // path (host side, like the driver's own post-build optimisation passes behind PREFER_FAST_TRACE).
-    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u);
+    // path -- on the device too (wide_collapse.hip); nothing but four statistics words comes back to the host.
+    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide);
     if(rc != VKRT_OK)
       return fail(rc, "LBVH build failed: %s", r.error.c_str());
     s->info.triangle_count = r.triCount;
     s->dev.triCount = r.triCount;
-    if(wide && r.triCount > 0)
+    if(wide && r.hasWide)
     {
-      // download the binary tree (device layout == host layout of BuiltBvh) and the sorted triangle records
+      (void)hipFree(r.nodes); (void)hipFree(r.tris); (void)hipFree(r.triShade);
+      s->accelNodes = r.wide.nodes;
+      s->accelTris = r.wide.tris;
+      s->accelShade = r.wide.triShade;
+      s->dev.nodes = (const float4*)s->accelNodes;
+      s->dev.tris = (const float4*)s->accelTris;
+      s->dev.triShade = (const uint4*)s->accelShade;
+      s->dev.layout = 1;
+      s->dev.rootRef = 0;
+      s->dev.stackCap = 2 * (r.wide.maxDepth + 1);  // at most one pending group per level (uint2 entries = 2 words)
+      s->info.node_count = r.wide.nodeCount;
+      s->info.max_depth = r.wide.maxDepth;
+      s->info.sah_cost = r.wide.sahCost;
+      s->info.node_bytes = (uint64_t)r.wide.nodeCount * 80;
+      s->info.triangle_bytes = (uint64_t)r.triCount * 48;
+    }
+    else if(wide && r.triCount > 0)
+    {
+      // fallback (a single triangle, or a radix tree too deep for the device collapse's level budget): download the binary
+      // tree (device layout == host layout of BuiltBvh) and the sorted triangle records, collapse on the host
       vkrt::BuiltBvh b2;
       b2.nodes.resize((size_t)r.nodeCount * 16);
       std::vector<float> trisHost((size_t)r.triCount * 12);
@@ -785,8 +804,44 @@ int fillParams(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* c
 }
 }  // namespace
 
+namespace {
+int gbufferImpl(vkrt_scene* s, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const float* viewMatrix, const vkrt_shard* shard,
+                const vkrt_gbuffer* out, const vkrt_nrd_planes* nrd, void* hip_stream);
+int hybridImpl(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
+               const vkrt_gbuffer* g, const vkrt_nrd_planes* nrd, float* accum, void* hip_stream);
+}  // namespace
+
 int vkrt_gbuffer_raycast(vkrt_scene* s, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const vkrt_shard* shard,
                          const vkrt_gbuffer* out, void* hip_stream)
+{
+  return gbufferImpl(s, clearColor, lightsCount, cam, nullptr, shard, out, nullptr, hip_stream);
+}
+
+int vkrt_gbuffer_raycast_nrd(vkrt_scene* s, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const float viewMatrix[16],
+                             const vkrt_shard* shard, const vkrt_gbuffer* out, const vkrt_nrd_planes* nrd, void* hip_stream)
+{
+  if(!nrd || !viewMatrix || !nrd->normalRoughness || !nrd->viewZ || !nrd->diffRadianceHitDist)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL NRD plane / view matrix");
+  return gbufferImpl(s, clearColor, lightsCount, cam, viewMatrix, shard, out, nrd, hip_stream);
+}
+
+int vkrt_hybrid_trace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
+                      const vkrt_gbuffer* g, float* accum, void* hip_stream)
+{
+  return hybridImpl(s, pc, cam, opts, shard, g, nullptr, accum, hip_stream);
+}
+
+int vkrt_hybrid_trace_nrd(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
+                          const vkrt_gbuffer* g, const vkrt_nrd_planes* nrd, float* accum, void* hip_stream)
+{
+  if(!nrd || !nrd->viewZ || !nrd->diffRadianceHitDist)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL NRD plane");
+  return hybridImpl(s, pc, cam, opts, shard, g, nrd, accum, hip_stream);
+}
+
+namespace {
+int gbufferImpl(vkrt_scene* s, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const float* viewMatrix, const vkrt_shard* shard,
+                const vkrt_gbuffer* out, const vkrt_nrd_planes* nrd, void* hip_stream)
 {
   if(!s || !clearColor || !cam || !shard || !out || !out->color || !out->position || !out->normal || !out->roughMetal)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -800,12 +855,19 @@ int vkrt_gbuffer_raycast(vkrt_scene* s, const float clearColor[4], int lightsCou
     return rc;
   if(P.localRows == 0)
     return VKRT_OK;
-  HIP_TRY(vkrt_launch_gbuffer(P, clearColor, lightsCount, out->color, out->position, out->normal, out->roughMetal, (hipStream_t)hip_stream));
+  NrdPlanes np{};
+  if(nrd)
+  {
+    np.normRough = nrd->normalRoughness; np.viewZ = nrd->viewZ; np.radHitD = nrd->diffRadianceHitDist;
+    memcpy(np.viewMatrix, viewMatrix, sizeof np.viewMatrix);
+  }
+  HIP_TRY(vkrt_launch_gbuffer(P, clearColor, lightsCount, out->color, out->position, out->normal, out->roughMetal, nrd ? &np : nullptr,
+                              (hipStream_t)hip_stream));
   return VKRT_OK;
 }
 
-int vkrt_hybrid_trace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
-                      const vkrt_gbuffer* g, float* accum, void* hip_stream)
+int hybridImpl(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
+               const vkrt_gbuffer* g, const vkrt_nrd_planes* nrd, float* accum, void* hip_stream)
 {
   if(!s || !pc || !cam || !shard || !g || !accum || !g->color || !g->position || !g->normal || !g->roughMetal)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -823,12 +885,18 @@ int vkrt_hybrid_trace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUnif
     return VKRT_OK;
   hipStream_t stream = (hipStream_t)hip_stream;
   HIP_TRY(hipEventRecord(s->evStart, stream));
-  HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, stream));
+  NrdPlanes np{};
+  if(nrd)
+  {
+    np.viewZ = nrd->viewZ; np.radHitD = nrd->diffRadianceHitDist;
+  }
+  HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, stream));
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->timed = true;
   s->wfTimed = false;
   return VKRT_OK;
 }
+}  // namespace
 
 int vkrt_post(int device, const PushConstantPost* pc, uint32_t n, const float* mainImg, const float* rtImg, float* out, void* hip_stream)
 {

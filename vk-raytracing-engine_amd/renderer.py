@@ -115,8 +115,10 @@ class Renderer:
         return image
 
     # ---- hybrid mode (reference rtMode == 0) ---------------------------------------------------------
-    def gbuffer_raycast(self, cam, width, height, lights_count=None, clear_color=(1.0, 1.0, 1.0, 1.0), shard=None, stream=None):
-        """Stand-in for rasterizeGltf: returns dict of torch CUDA planes color/position/normal [rows,W,4], roughMetal [rows,W,2]."""
+    def gbuffer_raycast(self, cam, width, height, lights_count=None, clear_color=(1.0, 1.0, 1.0, 1.0), shard=None, stream=None, view_matrix=None):
+        """Stand-in for rasterizeGltf: returns dict of torch CUDA planes color/position/normal [rows,W,4], roughMetal [rows,W,2].
+        view_matrix (16 floats, column-major pcRaster.viewMatrix): also the NRD front-end planes nrdNormalRoughness [rows,W,4],
+        nrdViewZ [rows,W], nrdRadianceHitDist [rows,W,4] (vkrt_gbuffer_raycast_nrd)."""
         import torch
 
         shard = shard or whole_image_shard(width, height)
@@ -128,6 +130,15 @@ class Renderer:
         gb = abi.Gbuffer(*(g[k].data_ptr() for k in ("color", "position", "normal", "roughMetal")))
         cc = (C.c_float * 4)(*clear_color)
         n = self.lights_count if lights_count is None else lights_count
+        if view_matrix is not None:
+            g["nrdNormalRoughness"] = torch.zeros((rows, width, 4), dtype=torch.float32, device=dev)
+            g["nrdViewZ"] = torch.zeros((rows, width), dtype=torch.float32, device=dev)
+            g["nrdRadianceHitDist"] = torch.zeros((rows, width, 4), dtype=torch.float32, device=dev)
+            nrd = abi.NrdPlanes(g["nrdNormalRoughness"].data_ptr(), g["nrdViewZ"].data_ptr(), g["nrdRadianceHitDist"].data_ptr())
+            vm = (C.c_float * 16)(*[float(v) for v in view_matrix])
+            _check(self.lib.vkrt_gbuffer_raycast_nrd(self._h, C.byref(cc), n, C.byref(cam), C.byref(vm), C.byref(shard), C.byref(gb), C.byref(nrd),
+                                                     C.c_void_p(stream.cuda_stream)), "vkrt_gbuffer_raycast_nrd")
+            return g
         _check(self.lib.vkrt_gbuffer_raycast(self._h, C.byref(cc), n, C.byref(cam), C.byref(shard), C.byref(gb), C.c_void_p(stream.cuda_stream)),
                "vkrt_gbuffer_raycast")
         return g
@@ -143,6 +154,11 @@ class Renderer:
         stream = stream or torch.cuda.current_stream(accum.device)
         gb = abi.Gbuffer(*(gbuffer[k].data_ptr() for k in ("color", "position", "normal", "roughMetal")))
         opts = abi.TraceOpts(seed & 0xFFFFFFFF, flags)
+        if "nrdViewZ" in gbuffer:  # planes from gbuffer_raycast(view_matrix=...): also pack the REBLUR input (rgen:273-281)
+            nrd = abi.NrdPlanes(gbuffer["nrdNormalRoughness"].data_ptr(), gbuffer["nrdViewZ"].data_ptr(), gbuffer["nrdRadianceHitDist"].data_ptr())
+            _check(self.lib.vkrt_hybrid_trace_nrd(self._h, C.byref(pc), C.byref(cam), C.byref(opts), C.byref(shard), C.byref(gb), C.byref(nrd),
+                                                  C.c_void_p(accum.data_ptr()), C.c_void_p(stream.cuda_stream)), "vkrt_hybrid_trace_nrd")
+            return accum
         _check(self.lib.vkrt_hybrid_trace(self._h, C.byref(pc), C.byref(cam), C.byref(opts), C.byref(shard), C.byref(gb),
                                           C.c_void_p(accum.data_ptr()), C.c_void_p(stream.cuda_stream)), "vkrt_hybrid_trace")
         return accum
