@@ -7,20 +7,28 @@
 //   k_wf_traverse      one thread per queued ray, batch-synchronous: the 64 rays of a wave start together, so the
 //                      top tree levels are fetched as coalesced/broadcast loads; lanes that finish early take over
 //                      pending subtrees of their neighbours (traverse_share.h).  Workgroups are one wave and
-//                      homogeneous: the first blocks take the closest-hit stream (rgen:64-75), the rest the shadow
-//                      stream (rgen:85-97, any-hit).  Per-lane stacks in LDS.  Software stand-in for traceRayEXT.
-//   k_wf_shade         one launch for both result streams.  Closest-hit workgroups (dispatched first): one thread per
-//                      closest-hit result, rchit / rmiss, then either a shadow-ray request or the segment accumulation
-//                      (rgen:99-120).  Shadow-result workgroups: accumulation, next segment / sample / pixel store.
+//                      homogeneous in ray kind: closest-hit rays first (rgen:64-75), then shadow rays (rgen:85-97, any-hit).
+//                      Per-lane stacks in LDS.  Software stand-in for traceRayEXT.
+//   k_wf_shade         one launch for the three result streams: rchit / rmiss, the segment accumulation (rgen:99-120),
+//                      the next ray(s) of the path.
 //
-// Path records MOVE with their queue position: a round reads the records of its two input streams front to back
+// Path records MOVE with their queue position: a round reads the records of its input streams front to back
 // and every surviving path writes its new record at the position a block-aggregated ballot compaction assigns
 // it in the next round's stream (ping-pong buffers).  All record traffic is therefore sequential; the state is
 // kept as structure-of-arrays planes of float4, so the 64 lanes of a wave read 1 KB contiguous per plane.
 // (The first version kept records in place and queued path ids: every record access was a random 16-byte gather
 // and the shade kernels ran at memory-system throughput, r01_experiments.md #24.)
 //
-// A frame = init + samples*depth*2 (traverse, shade, shade) rounds enqueued back to back on the caller's
+// Three streams (round 2).  The shadow ray of a diffuse segment and the closest-hit ray of the NEXT segment start at the same
+// point and neither needs the other's result: only the accumulation `hitValue += contrib` (rgen:99-102) waits for the shadow
+// ray.  A diffuse hit that is not the last segment of its sample therefore emits ONE "pair" record carrying both rays; they
+// are traced in the same round and the next shade step first finishes segment k (accumulate, weight, depth++), then shades
+// segment k+1's hit.  The rays traced, their order per path and every float operation are those of rgen's loop; only the
+// round in which a ray is traced changes.  A frame needs samples * (depth + 1) rounds instead of 2 * samples * depth
+// (144 instead of 256 on the bench workload), each with ~1.8x the rays, and a diffuse segment moves ~35 % fewer record bytes
+// (one record instead of a shadow record followed by a closest record).
+//
+// A frame = init + samples * (depth + 1) x (traverse, shade) enqueued back to back on the caller's
 // stream; stream counts stay on the device (no host synchronisation inside a frame).
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -40,32 +48,37 @@
 #define VKRT_FLAG_COUNT_WORK 2u  // = VKRT_TRACE_COUNT_TRAVERSAL (include/vkrt.h)
 
 // ---- streams ---------------------------------------------------------------------------------------------------------
-// Four streams [parity][type] (type 0 = paths whose next ray is the closest-hit ray, 1 = the shadow ray), each
-// WF_PLANES planes of `capacity` float4:
-//   plane 0  R0  ray origin.xyz, tmax                              written by the producer, read by k_wf_traverse
-//   plane 1  R1  ray direction.xyz, -                               (closest stream: = prd.rayDirection)
-//   plane 2  H0  hit t, u, v, instance id (-1 = miss / not occluded) written by k_wf_traverse
-//   plane 3  H1  triShade record of the hit triangle (closest stream only)
-//   plane 4  S0  path weight.xyz (closest: curWeight; shadow: weight after this segment), seed
-//   plane 5  S1  hitValue.xyz (radiance of the current sample), flags
-//   plane 6  S2  hitValues.xyz (sum over finished samples), px | lrow << 16
-//   plane 7  S3  shadow stream: clamped contribution of this segment if the light is visible (rgen:99-102), -
-//   plane 8  S4  shadow stream: direction of the next closest-hit ray (prd.rayDirection), -
+// Six streams [parity][type], each WF_PLANES planes of `capacity` float4.  type 0 "C": the path's next ray is a closest-hit
+// ray; type 1 "S": a shadow ray, and the segment it belongs to is the last of its sample; type 2 "P" (pair): the shadow ray
+// of segment k and the closest-hit ray of segment k + 1, both from the hit point of segment k.
+//   plane 0  R0  ray origin.xyz, tmax of the first ray (C: 10000; S, P: lightDist - 0.1)      written by the producer
+//   plane 1  R1  direction of the first ray (C: closest-hit ray; S, P: shadow ray), -
+//   plane 2  R2  P: direction of the closest-hit ray of the next segment (prd.rayDirection), -
+//   plane 3  H0  written by k_wf_traverse.  C: t, u, v, instance id (-1 = miss).  S: .w = 0 occluded / -1 not.
+//                P: .x = 1 occluded / 0 not (stored by the shadow lane), .y .z .w = u, v, instance id of the closest-hit ray
+//   plane 4  H1  C, P: triShade record of the closest hit
+//   plane 5  S0  path weight.xyz (C: curWeight; S, P: weight after the segment the shadow ray belongs to), seed
+//   plane 6  S1  hitValue.xyz (radiance of the current sample), flags
+//   plane 7  S2  hitValues.xyz (sum over finished samples), px | lrow << 16
+//   plane 8  S3  S, P: clamped contribution of the segment if its light is visible (rgen:99-102), -
 // flags: depth[0:8) | smpl[8:24) | isSpecular[25]
 #define WF_PLANES 9
-enum { WF_R0 = 0, WF_R1, WF_H0, WF_H1, WF_S0, WF_S1, WF_S2, WF_S3, WF_S4 };
+#define WF_TYPES 3
+enum { WF_R0 = 0, WF_R1, WF_R2, WF_H0, WF_H1, WF_S0, WF_S1, WF_S2, WF_S3 };
+enum { WF_C = 0, WF_S = 1, WF_P = 2 };
 
 VKRT_DEV float4* plane(const WfBuffers& B, int parity, int type, int k)
 {
-  return B.planes + ((size_t)((parity * 2 + type) * WF_PLANES + k)) * B.capacity;
+  return B.planes + ((size_t)((parity * WF_TYPES + type) * WF_PLANES + k)) * B.capacity;
 }
+VKRT_DEV unsigned* countOf(const WfBuffers& B, int parity, int type) { return &B.ctrl[parity * 4 + type]; }
 
 VKRT_DEV unsigned packFlags(const LaneState& L)
 {
   return (L.prd.depth & 0xffu) | (((unsigned)L.smpl & 0xffffu) << 8) | ((L.prd.isSpecular ? 1u : 0u) << 25);
 }
 
-// state common to both streams (S0..S2) -> lane
+// state common to all streams (S0..S2) -> lane
 VKRT_DEV void loadCommon(const TraceParams& P, const WfBuffers& B, int parity, int type, unsigned i, LaneState& L)
 {
   const float4 s0 = plane(B, parity, type, WF_S0)[i], s1 = plane(B, parity, type, WF_S1)[i], s2 = plane(B, parity, type, WF_S2)[i];
@@ -86,43 +99,49 @@ VKRT_DEV void loadCommon(const TraceParams& P, const WfBuffers& B, int parity, i
   L.stage = 0;
 }
 
-// a path whose next ray is the closest-hit ray (rgen:64-75) -> slot i of the closest stream
-VKRT_DEV void storeClosest(const WfBuffers& B, int parity, unsigned i, const LaneState& L)
+VKRT_DEV void storeState(const WfBuffers& B, int parity, int type, unsigned i, const LaneState& L, f3 weight)
 {
-  plane(B, parity, 0, WF_R0)[i] = make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, 10000.0f);
-  plane(B, parity, 0, WF_R1)[i] = make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f);
-  plane(B, parity, 0, WF_S0)[i] = make_float4(L.curWeight.x, L.curWeight.y, L.curWeight.z, __uint_as_float(L.prd.seed));
-  plane(B, parity, 0, WF_S1)[i] = make_float4(L.hitValue.x, L.hitValue.y, L.hitValue.z, __uint_as_float(packFlags(L)));
-  plane(B, parity, 0, WF_S2)[i] = make_float4(L.hitValues.x, L.hitValues.y, L.hitValues.z, __uint_as_float(L.px | (L.lrow << 16)));
+  plane(B, parity, type, WF_S0)[i] = make_float4(weight.x, weight.y, weight.z, __uint_as_float(L.prd.seed));
+  plane(B, parity, type, WF_S1)[i] = make_float4(L.hitValue.x, L.hitValue.y, L.hitValue.z, __uint_as_float(packFlags(L)));
+  plane(B, parity, type, WF_S2)[i] = make_float4(L.hitValues.x, L.hitValues.y, L.hitValues.z, __uint_as_float(L.px | (L.lrow << 16)));
 }
 
-// a path waiting for its shadow ray (rgen:85-97) -> slot i of the shadow stream
-VKRT_DEV void storeShadow(const WfBuffers& B, int parity, unsigned i, const LaneState& L, f3 contrib, f3 nextWeight)
+// a path whose next ray is the closest-hit ray (rgen:64-75) -> slot i of stream C
+VKRT_DEV void storeClosest(const WfBuffers& B, int parity, unsigned i, const LaneState& L)
 {
-  plane(B, parity, 1, WF_R0)[i] = make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, L.prd.lightDist - 0.1f);
-  plane(B, parity, 1, WF_R1)[i] = make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, 0.0f);
-  plane(B, parity, 1, WF_S0)[i] = make_float4(nextWeight.x, nextWeight.y, nextWeight.z, __uint_as_float(L.prd.seed));
-  plane(B, parity, 1, WF_S1)[i] = make_float4(L.hitValue.x, L.hitValue.y, L.hitValue.z, __uint_as_float(packFlags(L)));
-  plane(B, parity, 1, WF_S2)[i] = make_float4(L.hitValues.x, L.hitValues.y, L.hitValues.z, __uint_as_float(L.px | (L.lrow << 16)));
-  plane(B, parity, 1, WF_S3)[i] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
-  plane(B, parity, 1, WF_S4)[i] = make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f);
+  plane(B, parity, WF_C, WF_R0)[i] = make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, 10000.0f);
+  plane(B, parity, WF_C, WF_R1)[i] = make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f);
+  storeState(B, parity, WF_C, i, L, L.curWeight);
+}
+
+// a path waiting for the shadow ray of its current segment (rgen:85-97) -> slot i of stream S (last segment of the sample)
+// or, with the closest-hit ray of the next segment riding along, of stream P
+VKRT_DEV void storeShadow(const WfBuffers& B, int parity, int type, unsigned i, const LaneState& L, f3 contrib, f3 nextWeight)
+{
+  plane(B, parity, type, WF_R0)[i] = make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, L.prd.lightDist - 0.1f);
+  plane(B, parity, type, WF_R1)[i] = make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, 0.0f);
+  if(type == WF_P)
+    plane(B, parity, type, WF_R2)[i] = make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f);
+  storeState(B, parity, type, i, L, nextWeight);
+  plane(B, parity, type, WF_S3)[i] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
 }
 
 // Block-aggregated slot assignment in the next round's streams: ballot + popcount inside each wave, wave totals
 // combined through LDS, ONE global atomic per workgroup and stream (the count is a single word: per-wave atomics
-// serialise near 88/us, MI355X_MICROARCH.md "dequeue").  Must be called by every thread of the block; a thread sets
-// at most one of toC / toS and gets its slot back.  The slots of a block are contiguous, in lane order.  wsum: LDS [2*(nw+1)].
-VKRT_DEV unsigned claimSlots(unsigned* cntC, unsigned* cntS, bool toC, bool toS, unsigned lane, unsigned* wsum)
+// serialise near 88/us, MI355X_MICROARCH.md "dequeue").  Must be called by every thread of the block; `to` = the stream the
+// thread's path goes to (WF_C / WF_S / WF_P) or -1; returns its slot there.  The slots of a block are contiguous per stream,
+// in lane order.  wsum: LDS [WF_TYPES * (nw + 1)].
+VKRT_DEV unsigned claimSlots(const WfBuffers& B, int parity, int to, unsigned lane, unsigned* wsum)
 {
   const unsigned wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const unsigned long long mC = __ballot(toC), mS = __ballot(toS);
+  const unsigned long long m[WF_TYPES] = {__ballot(to == WF_C), __ballot(to == WF_S), __ballot(to == WF_P)};
   if(lane == 0)
   {
-    wsum[wave] = (unsigned)__popcll(mC);
-    wsum[nw + 1 + wave] = (unsigned)__popcll(mS);
+#pragma unroll
+    for(int t = 0; t < WF_TYPES; t++) wsum[t * (nw + 1) + wave] = (unsigned)__popcll(m[t]);
   }
   __syncthreads();
-  if(threadIdx.x < 2)
+  if(threadIdx.x < WF_TYPES)
   {
     unsigned* w = wsum + threadIdx.x * (nw + 1);
     unsigned tot = 0;
@@ -132,15 +151,14 @@ VKRT_DEV unsigned claimSlots(unsigned* cntC, unsigned* cntS, bool toC, bool toS,
       w[k] = tot;
       tot += c;
     }
-    w[nw] = tot ? atomicAdd(threadIdx.x == 0 ? cntC : cntS, tot) : 0u;
+    w[nw] = tot ? atomicAdd(countOf(B, parity, (int)threadIdx.x), tot) : 0u;
   }
   __syncthreads();
+  if(to < 0)
+    return 0u;
   const unsigned long long below = (1ull << lane) - 1ull;
-  if(toC)
-    return wsum[nw] + wsum[wave] + (unsigned)__popcll(mC & below);
-  if(toS)
-    return wsum[2 * nw + 1] + wsum[nw + 1 + wave] + (unsigned)__popcll(mS & below);
-  return 0u;
+  const unsigned long long mine = to == WF_C ? m[0] : to == WF_S ? m[1] : m[2];
+  return wsum[to * (nw + 1) + nw] + wsum[to * (nw + 1) + wave] + (unsigned)__popcll(mine & below);
 }
 
 // ---- init: raytrace.rgen:27-60 for every pixel of the shard -------------------------------------------------
@@ -170,8 +188,8 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_init(const TraceParams P, const
       }
     }
   }
-  __shared__ unsigned wsum[2 * (WF_BLOCK / 64 + 1)];
-  const unsigned slot = claimSlots(&B.ctrl[0], &B.ctrl[1], alive, false, lane, wsum);
+  __shared__ unsigned wsum[WF_TYPES * (WF_BLOCK / 64 + 1)];
+  const unsigned slot = claimSlots(B, 0, alive ? WF_C : -1, lane, wsum);
   if(alive)
     storeClosest(B, 0, slot, L);
   __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
@@ -179,70 +197,94 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_init(const TraceParams P, const
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 6, red);
 }
 
-// hit of a finished walk -> H0 (+ H1 for closest hits) of its stream slot
-VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int type, unsigned qi, const RayHit& hit)
+// Ray kinds a traversal workgroup can hold, in dispatch order: heavy closest-hit walks first, any-hit walks behind them.
+enum { WF_K_CLOSEST_C = 0, WF_K_CLOSEST_P = 1, WF_K_SHADOW_S = 2, WF_K_SHADOW_P = 3 };
+
+// result of a finished walk -> its record
+VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int kind, unsigned qi, const RayHit& hit)
 {
-  int inst = hit.slot >= 0 ? 0 : -1;
-  if(type == 0 && hit.slot >= 0)
+  if(kind == WF_K_SHADOW_S)
+    plane(B, par, WF_S, WF_H0)[qi] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(hit.slot >= 0 ? 0 : -1));
+  else if(kind == WF_K_SHADOW_P)
+    ((float*)&plane(B, par, WF_P, WF_H0)[qi])[0] = __int_as_float(hit.slot >= 0 ? 1 : 0);  // the closest-hit lane of the record owns .yzw
+  else
   {
-    // first hops of the hit shader's attribute fetch, taken here: the triangle's shading record and its instance id
-    // travel with the hit, so the closest-hit shading starts at the vertex / material loads
-    const uint4 ts = P.sc.triShade[hit.slot];
-    inst = __float_as_int(P.sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
-    plane(B, par, 0, WF_H1)[qi] = make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w));
+    const int type = kind == WF_K_CLOSEST_C ? WF_C : WF_P;
+    int inst = -1;
+    if(hit.slot >= 0)
+    {
+      // first hops of the hit shader's attribute fetch, taken here: the triangle's shading record and its instance id
+      // travel with the hit, so the closest-hit shading starts at the vertex / material loads
+      const uint4 ts = P.sc.triShade[hit.slot];
+      inst = __float_as_int(P.sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
+      plane(B, par, type, WF_H1)[qi] = make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w));
+    }
+    float* h = (float*)&plane(B, par, type, WF_H0)[qi];
+    if(type == WF_C)
+      plane(B, par, WF_C, WF_H0)[qi] = make_float4(hit.t, hit.u, hit.v, __int_as_float(inst));
+    else
+    {
+      h[1] = hit.u; h[2] = hit.v; h[3] = __int_as_float(inst);
+    }
   }
-  plane(B, par, type, WF_H0)[qi] = make_float4(hit.t, hit.u, hit.v, __int_as_float(inst));
 }
 
-// ---- traversal: one thread per queued ray, workgroups homogeneous in ray type -----------------------------------
+// ---- traversal: one thread per queued ray, workgroups homogeneous in ray kind -----------------------------------
 template <bool COUNT, bool WIDE, int TB>
 __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
 {
   extern __shared__ int lds_stack[];
   const int par = round & 1;
-  const unsigned countC = B.ctrl[par * 2 + 0], countS = B.ctrl[par * 2 + 1];
+  const unsigned cC = *countOf(B, par, WF_C), cS = *countOf(B, par, WF_S), cP = *countOf(B, par, WF_P);
   if(blockIdx.x == 0 && threadIdx.x == 0)
   {
-    B.ctrl[(par ^ 1) * 2 + 0] = 0u;  // next round's counts; this round's shade kernels claim slots from them
-    B.ctrl[(par ^ 1) * 2 + 1] = 0u;
+    for(int t = 0; t < WF_TYPES; t++) *countOf(B, par ^ 1, t) = 0u;  // next round's counts; this round's shade kernel claims slots from them
     // every slot below the counts is traced exactly once: the ray counters of the launch are the stream counts
-    if(countC) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][0], (unsigned long long)countC);
-    if(countS) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][1], (unsigned long long)countS);
+    if(cC + cP) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][0], (unsigned long long)cC + cP);
+    if(cS + cP) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][1], (unsigned long long)cS + cP);
   }
-  const unsigned nbC = (countC + TB - 1) / TB, nbS = (countS + TB - 1) / TB;
-  if(blockIdx.x >= nbC + nbS)
-    return;
-  const bool anyHit = blockIdx.x >= nbC;  // workgroup-uniform
-  const int type = anyHit ? 1 : 0;
-  const unsigned qi = (anyHit ? blockIdx.x - nbC : blockIdx.x) * TB + threadIdx.x;
-  const unsigned count = anyHit ? countS : countC;
+  // block ranges: [closest rays of C][closest rays of P][shadow rays of S][shadow rays of P]
+  const unsigned nC = (cC + TB - 1) / TB, nP = (cP + TB - 1) / TB, nS = (cS + TB - 1) / TB;
+  unsigned blk = blockIdx.x;
+  int kind;
+  unsigned count;
+  if(blk < nC) { kind = WF_K_CLOSEST_C; count = cC; }
+  else if((blk -= nC) < nP) { kind = WF_K_CLOSEST_P; count = cP; }
+  else if((blk -= nP) < nS) { kind = WF_K_SHADOW_S; count = cS; }
+  else if((blk -= nS) < nP) { kind = WF_K_SHADOW_P; count = cP; }
+  else return;
+  const bool anyHit = kind >= WF_K_SHADOW_S;  // workgroup-uniform
+  const int type = kind == WF_K_CLOSEST_C ? WF_C : kind == WF_K_SHADOW_S ? WF_S : WF_P;
+  const unsigned qi = blk * TB + threadIdx.x;
+  const bool valid = qi < count;
+  // the ray of this lane: origin from R0; the shadow ray of a pair record and every C / S ray take R1 and R0.w, the closest-hit
+  // ray of a pair record takes R2 and the closest-hit tmax
+  float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+  if(valid)
+  {
+    r0 = plane(B, par, type, WF_R0)[qi];
+    r1 = plane(B, par, type, kind == WF_K_CLOSEST_P ? WF_R2 : WF_R1)[qi];
+    if(kind == WF_K_CLOSEST_P)
+      r0.w = 10000.0f;
+  }
   TravCount tc;
   __shared__ int shareLds[VKRT_SHARE_LDS_WORDS];
+  RayHit hit;
   if(WIDE && TB == 64 && P.sc.shareMinIdle != 0u && P.sc.triThreshold != 0u)  // launch-uniform
   {
     // the whole wave walks together: lanes past the end of the stream have no ray of their own but help
-    const bool valid = qi < count;
-    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-    if(valid)
-    {
-      r0 = plane(B, par, type, WF_R0)[qi];
-      r1 = plane(B, par, type, WF_R1)[qi];
-    }
-    RayHit hit;
     uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
     if(anyHit)
       traverse_wide8_share<COUNT, true>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
     else
       traverse_wide8_share<COUNT, false>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
     if(valid)
-      storeHit(P, B, par, type, qi, hit);
+      storeHit(P, B, par, kind, qi, hit);
   }
-  else if(qi < count)
+  else if(valid)
   {
-    const float4 r0 = plane(B, par, type, WF_R0)[qi], r1 = plane(B, par, type, WF_R1)[qi];
-    RayHit hit;
     traverse_any<COUNT, WIDE>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc);
-    storeHit(P, B, par, type, qi, hit);
+    storeHit(P, B, par, kind, qi, hit);
   }
   if(COUNT)
   {
@@ -252,48 +294,59 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
   }
 }
 
-// ---- shade, closest-hit results: rchit / rmiss, then shadow request or accumulation (heavy; few waves/SIMD) ---------
+// ---- shade, results of streams C and P: [finish segment k,] rchit / rmiss of the traced closest-hit ray, then the next ray(s) ----
 // (Regrouping the 256 results of a workgroup by lobe through LDS between the hit shader's front half and its diffuse / specular
 // tail -- closestHitFront / closestHitLobe / closestHitTail in shade.h -- so that a wave runs one branch only was built and
 // measured in round 2: bit-identical images, ~30 % fewer VALU instructions, no change in kernel time (5.94 vs 5.91 ms per
 // 4-spp frame): the stage is bound by its stream traffic to HBM and the latency of its gathers, not by issue.  Removed again;
 // profiles/r02_experiments.md #52.)
-VKRT_DEV void shadeClosestBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
+template <bool PAIR>
+VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
 {
+  const int type = PAIR ? WF_P : WF_C;
   const unsigned lane = lane_id();
   const unsigned qi = block * WF_BLOCK + threadIdx.x;
   __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
   st.lut = ldsTexelLut(P.sc, lut);
-  __shared__ unsigned wsum[2 * (WF_BLOCK / 64 + 1)];
-  bool toClosest = false, toShadow = false;
+  __shared__ unsigned wsum[WF_TYPES * (WF_BLOCK / 64 + 1)];
+  int to = -1;
   LaneState L;
   f3 contrib = mk3(0.0f), nextWeight = mk3(0.0f);
   if(qi < count)
   {
-    loadCommon(P, B, par, 0, qi, L);
-    const float4 r1 = plane(B, par, 0, WF_R1)[qi], h = plane(B, par, 0, WF_H0)[qi], t4 = plane(B, par, 0, WF_H1)[qi];
-    L.prd.rayDirection = mk3(r1.x, r1.y, r1.z);
-    L.prd.rayOrigin = mk3(0.0f);  // rchit / rmiss do not read it
+    loadCommon(P, B, par, type, qi, L);
+    const float4 h = plane(B, par, type, WF_H0)[qi], t4 = plane(B, par, type, WF_H1)[qi];
+    const float4 rd = plane(B, par, type, PAIR ? WF_R2 : WF_R1)[qi];
+    L.prd.rayDirection = mk3(rd.x, rd.y, rd.z);  // direction of the closest-hit ray that was traced
+    L.prd.rayOrigin = mk3(0.0f);                 // rchit / rmiss do not read it
+    if(PAIR)
+    {
+      // finish segment k first (rgen:99-116): its shadow ray came back with this record.  S0 holds the weight after it;
+      // the segment is never the last of its sample (emission rule below), so advanceSegment only accumulates and steps depth
+      const float4 s3 = plane(B, par, WF_P, WF_S3)[qi];
+      const bool shadowHit = __float_as_int(h.x) != 0;
+      (void)advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
+    }
     RayHit hit;
-    hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.slot = __float_as_int(h.w);  // instance id of the hit (>= 0) or -1
+    hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.slot = __float_as_int(h.w);  // instance id of the hit (>= 0) or -1; t is not used by the shaders
     const uint4 ts = make_uint4(__float_as_uint(t4.x), __float_as_uint(t4.y), __float_as_uint(t4.z), __float_as_uint(t4.w));
     if(hit.slot >= 0)
       closestHitShaderInst(P.sc, P.pc, hit, (uint32_t)hit.slot, ts, L.prd.rayDirection, L.prd, st);
     else
       missShader(P.pc, L.prd);
     segmentTerms(L, contrib, nextWeight);
-    if(!L.prd.isSpecular && L.prd.depth != 100u)  // rgen:79
-      toShadow = true;
+    if(!L.prd.isSpecular && L.prd.depth != 100u)  // rgen:79: a shadow ray decides whether this segment contributes
+      to = (L.prd.depth + 1u < (uint32_t)P.pc.depth) ? WF_P : WF_S;  // not the last segment: the next closest-hit ray rides along
     else
-      toClosest = advanceSegment(P, L, false, contrib, nextWeight);
+      to = advanceSegment(P, L, false, contrib, nextWeight) ? WF_C : -1;
   }
-  const unsigned slot = claimSlots(&B.ctrl[(par ^ 1) * 2 + 0], &B.ctrl[(par ^ 1) * 2 + 1], toClosest, toShadow, lane, wsum);
-  if(toClosest)
+  const unsigned slot = claimSlots(B, par ^ 1, to, lane, wsum);
+  if(to == WF_C)
     storeClosest(B, par ^ 1, slot, L);
-  if(toShadow)
-    storeShadow(B, par ^ 1, slot, L, contrib, nextWeight);
+  else if(to >= 0)
+    storeShadow(B, par ^ 1, to, slot, L, contrib, nextWeight);
   if(P.flags & VKRT_FLAG_COUNT_WORK)  // launch-uniform: hit / lobe / texture-tap tallies are instrumentation, not needed for the ray rate
   {
     __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
@@ -302,48 +355,48 @@ VKRT_DEV void shadeClosestBlock(const TraceParams& P, const WfBuffers& B, const 
   }
 }
 
-// ---- shade, shadow results: accumulate the segment (rgen:99-120), next sample or pixel store (light; many waves) --------
+// ---- shade, results of stream S: the last segment of a sample (rgen:99-120), next sample or pixel store (light; many waves) ----
 VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
 {
   const unsigned lane = lane_id();
   const unsigned qi = block * WF_BLOCK + threadIdx.x;
-  __shared__ unsigned wsum[2 * (WF_BLOCK / 64 + 1)];
+  __shared__ unsigned wsum[WF_TYPES * (WF_BLOCK / 64 + 1)];
   bool toClosest = false;
   LaneState L;
   if(qi < count)
   {
-    loadCommon(P, B, par, 1, qi, L);  // S0 holds the weight after this segment
-    const float4 r0 = plane(B, par, 1, WF_R0)[qi], h = plane(B, par, 1, WF_H0)[qi];
-    const float4 s3 = plane(B, par, 1, WF_S3)[qi], s4 = plane(B, par, 1, WF_S4)[qi];
-    L.prd.rayOrigin = mk3(r0.x, r0.y, r0.z);  // the shadow ray started at the hit point = origin of the next segment
-    L.prd.rayDirection = mk3(s4.x, s4.y, s4.z);
+    loadCommon(P, B, par, WF_S, qi, L);  // S0 holds the weight after this segment
+    const float4 h = plane(B, par, WF_S, WF_H0)[qi], s3 = plane(B, par, WF_S, WF_S3)[qi];
+    L.prd.rayOrigin = mk3(0.0f);     // the sample ends here: startSample sets the next ray, or the pixel is stored
+    L.prd.rayDirection = mk3(0.0f);
     const bool shadowHit = __float_as_int(h.w) >= 0;
     toClosest = advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
   }
-  const unsigned slot = claimSlots(&B.ctrl[(par ^ 1) * 2 + 0], &B.ctrl[(par ^ 1) * 2 + 1], toClosest, false, lane, wsum);
+  const unsigned slot = claimSlots(B, par ^ 1, toClosest ? WF_C : -1, lane, wsum);
   if(toClosest)
     storeClosest(B, par ^ 1, slot, L);
 }
 
-// One launch shades both result streams of a round: the heavy closest-hit workgroups are dispatched first, the light
+// One launch shades the three result streams of a round: the heavy workgroups (C, then P) are dispatched first, the light
 // shadow-result workgroups fill in behind them.
 __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
 {
   const int par = round & 1;
-  const unsigned countC = B.ctrl[par * 2 + 0], countS = B.ctrl[par * 2 + 1];
-  const unsigned nbC = (countC + WF_BLOCK - 1) / WF_BLOCK, nbS = (countS + WF_BLOCK - 1) / WF_BLOCK;
-  if(blockIdx.x >= nbC + nbS)
-    return;
-  if(blockIdx.x < nbC)
-    shadeClosestBlock(P, B, par, countC, blockIdx.x);
-  else
-    shadeShadowBlock(P, B, par, countS, blockIdx.x - nbC);
+  const unsigned cC = *countOf(B, par, WF_C), cS = *countOf(B, par, WF_S), cP = *countOf(B, par, WF_P);
+  const unsigned nC = (cC + WF_BLOCK - 1) / WF_BLOCK, nP = (cP + WF_BLOCK - 1) / WF_BLOCK, nS = (cS + WF_BLOCK - 1) / WF_BLOCK;
+  unsigned blk = blockIdx.x;
+  if(blk < nC)
+    shadeHitBlock<false>(P, B, par, cC, blk);
+  else if((blk -= nC) < nP)
+    shadeHitBlock<true>(P, B, par, cP, blk);
+  else if((blk -= nP) < nS)
+    shadeShadowBlock(P, B, par, cS, blk);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 size_t vkrt_wf_state_bytes(uint32_t pathCapacity)
 {
-  return (size_t)pathCapacity * 4 * WF_PLANES * sizeof(float4) + 256 * VKRT_WF_MAX_SUBFRAMES;
+  return (size_t)pathCapacity * 2 * WF_TYPES * WF_PLANES * sizeof(float4) + 256 * VKRT_WF_MAX_SUBFRAMES;
 }
 
 void vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B)
@@ -382,7 +435,7 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const
     Q.tileCount = t1 - t0;
     WfBuffers Bj;
     Bj.ctrl = B.ctrl + 64 * j;
-    Bj.planes = B.planes + (size_t)4 * WF_PLANES * ((size_t)t0 * 64u);
+    Bj.planes = B.planes + (size_t)2 * WF_TYPES * WF_PLANES * ((size_t)t0 * 64u);
     Bj.capacity = Q.tileCount * 64u;
     if((e = hipStreamWaitEvent(async->streams[j], async->fork, 0)) != hipSuccess) return e;
     if((e = launchSubframe(Q, Bj, travBlock, count, async->streams[j], nullptr)) != hipSuccess) return e;
@@ -404,13 +457,14 @@ static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsig
     return hipGetLastError();
   const dim3 bb(WF_BLOCK);
   const bool wide = P.sc.layout == 1u;
-  // a path issues at most 2 rays per segment, depth segments per sample, samples per pixel
-  const int rounds = 2 * P.pc.samples * P.pc.depth;
+  // a sample takes at most depth + 1 rounds: its first closest-hit ray, then one round per further segment (the shadow ray of
+  // segment k travels with the closest-hit ray of segment k + 1), then the shadow ray of its last segment
+  const int rounds = P.pc.samples * (P.pc.depth + 1);
   if(timing)
     timing->used = 0;
-  // closest + shadow entries never exceed the number of paths; +2 blocks for the two partial tails.
+  // every path holds one record and a record at most two rays; +4 blocks for the partial tails of the four ray kinds.
   // One wavefront per workgroup by default: a finished wave frees its slot and LDS without waiting for three others.
-  const dim3 tg((work + travBlock - 1) / travBlock + 2), tb(travBlock);
+  const dim3 tg(2 * ((work + travBlock - 1) / travBlock) + 4), tb(travBlock);
   const size_t tlds = (size_t)P.sc.stackCap * travBlock * sizeof(int);
   for(int r = 0; r < rounds; r++)
   {
@@ -439,7 +493,7 @@ static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsig
       (void)hipEventRecord(timing->events[2 * timing->used + 1], stream);
       timing->used++;
     }
-    hipLaunchKernelGGL(k_wf_shade, dim3(blocks + 2), bb, 0, stream, P, B, r);
+    hipLaunchKernelGGL(k_wf_shade, dim3(blocks + 3), bb, 0, stream, P, B, r);
   }
   return hipGetLastError();
 }
