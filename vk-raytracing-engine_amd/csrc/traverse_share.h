@@ -228,7 +228,12 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           T = stk[(cap - nPost) * stride];
           nPost--;
         }
-        if(T.y != 0u && !(ANYHIT && found))
+        // triangle step: with triThreshold > 1 the wave tests triangles only when that many of its walking lanes hold a pending
+        // group, or none of them has node work left (experiment #57; 1 = every iteration, the default)
+        bool triStep = true;
+        if(sc.triThreshold > 1u)
+          triStep = (unsigned)__popcll(__ballot(T.y != 0u)) >= sc.triThreshold || __ballot((G.y & 0xff000000u) != 0u) == 0ull;
+        if(T.y != 0u && triStep && !(ANYHIT && found))
           testOne();
         if(ANYHIT && found)
           finished = true;
