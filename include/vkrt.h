@@ -188,7 +188,7 @@ void vkrt_scene_destroy(vkrt_scene* scene);
 enum vkrt_option {
   VKRT_OPT_MODE            = 1, /* 1 = wavefront pipeline (default), 0 = one persistent megakernel (BVH2 only) [build]; env VKRT_MODE=mega */
   VKRT_OPT_BVH_LAYOUT      = 2, /* 1 = 8-wide compressed nodes (default with the wavefront pipeline), 0 = BVH2 [build]; env VKRT_BVH=bvh2 */
-  VKRT_OPT_WF_SUBFRAMES    = 3, /* independent sub-frames of a launch on internal streams, 1..8 (default 2); env VKRT_WF_SUBFRAMES */
+  VKRT_OPT_WF_SUBFRAMES    = 3, /* independent sub-frames of a launch on internal streams, 1..8 (default 3); env VKRT_WF_SUBFRAMES */
   VKRT_OPT_WF_TRAV_BLOCK   = 4, /* threads per traversal workgroup: 64 (default), 128, 256; env VKRT_WF_TRAV_BLOCK */
   VKRT_OPT_WF_SHARE        = 5, /* idle lanes of a traversal wave needed before they adopt subtrees, 0 = off (default 16) [build]; env VKRT_WF_SHARE */
   VKRT_OPT_TRI_THRESHOLD   = 6, /* lanes with pending triangles before a wave tests them, 0 = test at once (default 1) [build]; env VKRT_TRI_THRESHOLD */

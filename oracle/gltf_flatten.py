@@ -24,8 +24,30 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
 import vkrt_amd  # noqa: E402
-from vkrt_amd.flat_scene import (FlatScene, LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE,  # noqa: E402
-                                 fallback_lights)
+from vkrt_amd.flat_scene import FlatScene, LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE  # noqa: E402  (containers only)
+
+
+def reference_fallback_lights():
+    """The oracle's OWN transcription of the lights loadGltfLights appends when a file has none (hello_vulkan.cpp:255-321:
+    one light near the origin of the nave and seven along +z; the commented-out entries at :249-254 and :261-284 are not part
+    of it).  Deliberately not shared with the product's table (vkrt_amd.flat_scene.fallback_lights, host/gltf_loader.cpp): a
+    test compares the three copies."""
+    rows = [((1.0, 5.0, -1.33), (1.0, 1.0, 1.0)),        # :255-260
+            ((0.0, 3.0, 67.0), (1.0, 0.01, 0.1)),        # :285-290
+            ((-1.3, 7.62, 59.0), (1.0, 1.0, 1.0)),       # :291-296
+            ((2.4, 2.05, 40.6), (1.0, 1.0, 1.0)),        # :297-302
+            ((-0.33, 6.85, 30.0), (1.0, 1.0, 1.0)),      # :303-308
+            ((-6.2, 9.6, 20.18), (1.0, 1.0, 1.0)),       # :309-314
+            ((-0.23, 6.93, 12.21), (1.0, 1.0, 0.0)),     # :315-320 (position), colour (1, 1, 0)
+            ((0.24, 3.03, 49.94), (0.0, 0.0, 1.0))]      # :321-326
+    L = np.zeros(len(rows), LIGHT_DTYPE)
+    for i, (pos, col) in enumerate(rows):
+        L[i]["position"] = pos
+        L[i]["color"] = col
+        L[i]["intensity"] = 50.0  # every fallback light: intensity 50, type 0 (point)
+        L[i]["type"] = 0
+    return L
+
 
 _COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
 _NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
@@ -251,7 +273,7 @@ def load_gltf(path, image_decoder=None):
             L[i]["intensity"] = np.float32(l.get("intensity", 1.0))
             L[i]["type"] = type_map.get(l.get("type", "point"), 0)
     else:
-        L = fallback_lights()
+        L = reference_fallback_lights()
 
     # ---- textures (createTextureImages, hello_vulkan.cpp:417-513) ------------------------------
     textures = []

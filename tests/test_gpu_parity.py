@@ -478,7 +478,7 @@ def test_scheduling_variants_and_repeats_are_bit_identical():
         assert hs[0] == hs[1], "repeat differs"
         print("HASH", hs[0])
     """)
-    variants = [{}, {"VKRT_WF_SUBFRAMES": "1"}, {"VKRT_WF_SUBFRAMES": "3"}, {"VKRT_WF_SHARE": "0"}, {"VKRT_WF_SHARE": "4"},
+    variants = [{}, {"VKRT_WF_SUBFRAMES": "1"}, {"VKRT_WF_SUBFRAMES": "2"}, {"VKRT_WF_SHARE": "0"}, {"VKRT_WF_SHARE": "4"},
                 {"VKRT_WF_TRAV_BLOCK": "256"}, {"VKRT_TRI_THRESHOLD": "0", "VKRT_WF_SHARE": "0"}, {"VKRT_BVH": "bvh2"}, {"VKRT_MODE": "mega"}]
     hashes = []
     for v in variants:
@@ -685,11 +685,11 @@ def test_scene_options_are_per_handle_and_do_not_change_pixels(atrium_small):
     flat, info, camkw = atrium_small
     W, H = 384, 216
     cam = default_camera(W, H, **camkw)
-    variants = [{}, {abi.VKRT_OPT_WF_SUBFRAMES: 1}, {abi.VKRT_OPT_WF_SUBFRAMES: 3}, {abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 1},
+    variants = [{}, {abi.VKRT_OPT_WF_SUBFRAMES: 1}, {abi.VKRT_OPT_WF_SUBFRAMES: 2}, {abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 0},
                 {abi.VKRT_OPT_WF_SHARE: 4, abi.VKRT_OPT_WF_SHARE_FLAGS: 1}, {abi.VKRT_OPT_WF_TRAV_BLOCK: 256}, {abi.VKRT_OPT_BVH_LAYOUT: 0},
                 {abi.VKRT_OPT_TRI_THRESHOLD: 0, abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_MODE: 0}]
     rs = [Renderer(flat, device=0, build="sah", options=v) for v in variants]
-    assert rs[1].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 1 and rs[0].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 2
+    assert rs[1].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 1 and rs[0].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 3
     with pytest.raises(VkrtError):
         rs[0].set_option(abi.VKRT_OPT_WF_TRAV_BLOCK, 100)
     with pytest.raises(VkrtError):

@@ -208,3 +208,16 @@ def test_bruteforce_equals_bvh_on_flat_axis_aligned_geometry():
         orc.render(pc, cam, W, H, seed=40 + f, rows=rows, image=a)
         orc.render(pc, cam, W, H, seed=40 + f, rows=rows, image=b, use_bvh=False)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_fallback_light_tables_are_independent_copies_that_agree():
+    """hello_vulkan.cpp:255-326 is transcribed three times (oracle/gltf_flatten.py, vkrt_amd.flat_scene, host/gltf_loader.cpp
+    through the C++ loader): a typo in one of them must show."""
+    import gltf_flatten
+    from vkrt_amd.flat_scene import fallback_lights
+
+    a, b = gltf_flatten.reference_fallback_lights(), fallback_lights()
+    assert a.shape == b.shape == (8,)
+    for k in ("position", "color", "intensity", "type"):
+        assert np.array_equal(a[k], b[k]), k
+    assert gltf_flatten.reference_fallback_lights is not fallback_lights

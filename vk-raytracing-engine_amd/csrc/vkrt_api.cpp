@@ -81,7 +81,7 @@ struct vkrt_scene
   WfTiming wfTiming{};
   bool wfTimed = false;
   // execution options (include/vkrt.h vkrt_option); index = option id
-  int opt[9] = {0, 1, 1, 2, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT};
+  int opt[9] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT};
   bool wavefront = true;  // execution mode the acceleration structure was built for (opt[VKRT_OPT_MODE] at vkrt_accel_build)
 };
 
