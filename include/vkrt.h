@@ -71,9 +71,11 @@ typedef struct vkrt_node {
 
 /* One sampled image: 8-bit RGBA, row-major, top row first (what tinygltf/stb hand the
  * reference, hello_vulkan.cpp:482-499).  is_srgb follows getImageFormat
- * (hello_vulkan.cpp:417-443).  Sampler: bilinear, REPEAT, LOD 0 (:448-454 and SURVEY
- * Appendix A 27-29).  textures[i] here is glTF texture i (already resolved to its
- * source image, :505-509). */
+ * (hello_vulkan.cpp:417-443).  Sampler (:448-454 and SURVEY Appendix A 27-29): linear, REPEAT;
+ * the ray tracing stages read LOD 0 (no derivatives there), the hybrid mode's G-buffer pass samples
+ * like the fragment shader it stands for -- implicit LOD over the mip chain the library generates at
+ * vkrt_scene_create (:499), anisotropy 4.  textures[i] here is glTF texture i (already resolved to
+ * its source image, :505-509). */
 typedef struct vkrt_texture {
   uint32_t       width;
   uint32_t       height;
@@ -193,7 +195,9 @@ enum vkrt_option {
   VKRT_OPT_WF_SHARE        = 5, /* idle lanes of a traversal wave needed before they adopt subtrees, 0 = off (default 16) [build]; env VKRT_WF_SHARE */
   VKRT_OPT_TRI_THRESHOLD   = 6, /* lanes with pending triangles before a wave tests them, 0 = test at once (default 1) [build]; env VKRT_TRI_THRESHOLD */
   VKRT_OPT_WF_SHARE_PERIOD = 7, /* sharing attempted on steps with (step & mask) == mask (default 0 = every step) [build]; env VKRT_WF_SHARE_PERIOD */
-  VKRT_OPT_WF_SHARE_FLAGS  = 8  /* bit 0: lanes with an empty stack also donate a pending child of their current group [build]; env VKRT_WF_SHARE_FLAGS */
+  VKRT_OPT_WF_SHARE_FLAGS  = 8, /* bit 0: lanes with an empty stack also donate a pending child of their current group [build]; env VKRT_WF_SHARE_FLAGS */
+  VKRT_OPT_GBUFFER_MIPS    = 9  /* NOT a scheduling knob: 1 (default) = vkrt_gbuffer_raycast samples textures like the fragment shader it replaces
+                                   (implicit LOD over the mip chain, anisotropy 4; hello_vulkan.cpp:448-454, :499), 0 = LOD 0; env VKRT_GBUFFER_MIPS */
 };
 int vkrt_scene_set_option(vkrt_scene* scene, int option, int value);
 int vkrt_scene_get_option(const vkrt_scene* scene, int option, int* value);
@@ -233,8 +237,11 @@ typedef struct vkrt_gbuffer {
   float* roughMetal; /* 2 floats/pixel eRoughMap: roughness, metalness after the rg16f round trip                        */
 } vkrt_gbuffer;
 /* Replaces the raster pass HelloVulkan::rasterizeGltf (hello_vulkan.cpp:583-615, vert_shader.vert,
- * frag_shader.frag) by a primary ray cast per pixel centre evaluating the same shader math (textures at
- * LOD 0).  lightsCount = PushConstantRaster.lightsCount. */
+ * frag_shader.frag) by a primary ray cast per pixel centre evaluating the same shader math.  texture() takes
+ * its LOD as in a fragment shader: dFdx / dFdy of the texture coordinate inside the pixel's 2x2 quad (the quad
+ * partner evaluated on the same triangle's plane), then the Vulkan scale-factor / LOD / anisotropy formulas
+ * with the reference's sampler (trilinear, maxAnisotropy 4); VKRT_OPT_GBUFFER_MIPS = 0 reads LOD 0 instead.
+ * lightsCount = PushConstantRaster.lightsCount. */
 int vkrt_gbuffer_raycast(vkrt_scene* scene, const float clearColor[4], int lightsCount, const GlobalUniforms* cam,
                          const vkrt_shard* shard, const vkrt_gbuffer* out, void* hip_stream);
 /* Replaces HelloVulkan::raytraceRasterizedScene (hello_vulkan.cpp:1450-1473 = vkCmdTraceRaysKHR over

@@ -116,6 +116,7 @@ class NpScene:
         c = np.arange(256, dtype=np.float64) / 255.0
         self._unorm = c.astype(F)
         self._srgb = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4).astype(F)
+        self._mips = {}
 
     # -- ray queries (software stand-in for traceRayEXT; what the driver does is not in the reference) --------------------
     def _mt(self, o, d, chunk=96):
@@ -164,6 +165,26 @@ class NpScene:
         return out
 
     # -- texture(): VkSampler of hello_vulkan.cpp:448-454 (LINEAR, REPEAT) at LOD 0 ------------------------------------
+    def _bilinear(self, img, is_srgb, uv):
+        """one LINEAR / REPEAT tap per row of uv (N,2) in the RGBA8 image img (h,w,4) -> (N,4) f32"""
+        h, w = img.shape[0], img.shape[1]
+        x = uv[:, 0] * F(w) - F(0.5)
+        y = uv[:, 1] * F(h) - F(0.5)
+        fx, fy = np.floor(x), np.floor(y)
+        ax, ay = (x - fx).astype(F), (y - fy).astype(F)
+        x0 = np.mod(fx.astype(np.int64), w)
+        y0 = np.mod(fy.astype(np.int64), h)
+        x1, y1 = np.mod(x0 + 1, w), np.mod(y0 + 1, h)
+        lut = self._srgb if is_srgb else self._unorm
+
+        def texel(yy, xx):
+            p = img[yy, xx]
+            return np.concatenate([lut[p[:, :3]], self._unorm[p[:, 3:4]]], 1)
+
+        t00, t10, t01, t11 = texel(y0, x0), texel(y0, x1), texel(y1, x0), texel(y1, x1)
+        wx0, wy0 = (F(1) - ax)[:, None], (F(1) - ay)[:, None]
+        return ((t00 * wx0 + t10 * ax[:, None]) * wy0 + (t01 * wx0 + t11 * ax[:, None]) * ay[:, None]).astype(F)
+
     def texture(self, tex_index, uv):
         """tex_index (N,) int (all >= 0 and valid), uv (N,2) f32 -> (N,4) f32"""
         out = np.ones((uv.shape[0], 4), F)
@@ -172,24 +193,89 @@ class NpScene:
             if ti < 0 or ti >= len(self.flat.textures):
                 continue  # the 1x1 white dummy (hello_vulkan.cpp:468-472)
             tx = self.flat.textures[int(ti)]
-            img = np.asarray(tx["rgba8"])
-            h, w = img.shape[0], img.shape[1]
-            x = uv[m, 0] * F(w) - F(0.5)
-            y = uv[m, 1] * F(h) - F(0.5)
-            fx, fy = np.floor(x), np.floor(y)
-            ax, ay = (x - fx).astype(F), (y - fy).astype(F)
-            x0 = np.mod(fx.astype(np.int64), w)
-            y0 = np.mod(fy.astype(np.int64), h)
-            x1, y1 = np.mod(x0 + 1, w), np.mod(y0 + 1, h)
-            lut = self._srgb if tx["is_srgb"] else self._unorm
+            out[m] = self._bilinear(np.asarray(tx["rgba8"]), bool(tx["is_srgb"]), uv[m])
+        return out
 
-            def texel(yy, xx):
-                p = img[yy, xx]
-                return np.concatenate([lut[p[:, :3]], self._unorm[p[:, 3:4]]], 1)
+    # -- the fragment shader's texture(): implicit LOD over the mip chain + anisotropy 4 (hello_vulkan.cpp:448-454, :499) --
+    def mip_chain(self, ti):
+        """Levels of texture ti: level L = linear blit of level L-1 to max(1, size // 2) (nvvk::cmdGenerateMipmaps), float64."""
+        if ti in self._mips:
+            return self._mips[ti]
+        tx = self.flat.textures[int(ti)]
+        srgb = bool(tx["is_srgb"])
+        chain = [np.asarray(tx["rgba8"])]
+        while chain[-1].shape[0] > 1 or chain[-1].shape[1] > 1:
+            src = chain[-1]
+            sh, sw = src.shape[0], src.shape[1]
+            dh, dw = max(1, sh // 2), max(1, sw // 2)
+            val = np.empty((sh, sw, 4), np.float64)            # decoded texel values (sRGB images blit in linear space)
+            val[..., :3] = (self._srgb if srgb else self._unorm)[src[..., :3]]
+            val[..., 3] = self._unorm[src[..., 3]]
+            # destination texel centres in unnormalised source coordinates, clamp-to-edge bilinear
+            sx = (np.arange(dw) + 0.5) * (sw / dw) - 0.5
+            sy = (np.arange(dh) + 0.5) * (sh / dh) - 0.5
+            x0f, y0f = np.floor(sx), np.floor(sy)
+            wx, wy = sx - x0f, sy - y0f
+            xa, xb = np.clip(x0f, 0, sw - 1).astype(np.int64), np.clip(x0f + 1, 0, sw - 1).astype(np.int64)
+            ya, yb = np.clip(y0f, 0, sh - 1).astype(np.int64), np.clip(y0f + 1, 0, sh - 1).astype(np.int64)
+            top = val[ya][:, xa] * (1 - wx)[None, :, None] + val[ya][:, xb] * wx[None, :, None]
+            bot = val[yb][:, xa] * (1 - wx)[None, :, None] + val[yb][:, xb] * wx[None, :, None]
+            lin = top * (1 - wy)[:, None, None] + bot * wy[:, None, None]
+            if srgb:
+                c = lin[..., :3]
+                lin[..., :3] = np.where(c <= 0.0031308, 12.92 * c, 1.055 * np.power(np.maximum(c, 0.0), 1.0 / 2.4) - 0.055)
+            chain.append(np.floor(np.clip(lin, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8))
+        self._mips[ti] = chain
+        return chain
 
-            t00, t10, t01, t11 = texel(y0, x0), texel(y0, x1), texel(y1, x0), texel(y1, x1)
-            wx0, wy0 = (F(1) - ax)[:, None], (F(1) - ay)[:, None]
-            out[m] = ((t00 * wx0 + t10 * ax[:, None]) * wy0 + (t01 * wx0 + t11 * ax[:, None]) * ay[:, None]).astype(F)
+    def texture_grad(self, tex_index, uv, grad):
+        """texture() with screen-space derivatives grad (N,4) = (dudx, dvdx, dudy, dvdy).  Vulkan 1.3 spec, Image Operations:
+        rho per axis in texels, eta = min(rho_max / rho_min, 4), N = ceil(eta) taps along the major axis at offsets
+        i / (N + 1) - 1/2, lambda = log2(rho_max / eta) clamped to the chain, linear blend of the two levels around it."""
+        out = np.ones((uv.shape[0], 4), F)
+        for ti in np.unique(tex_index):
+            m = np.nonzero(tex_index == ti)[0]
+            if ti < 0 or ti >= len(self.flat.textures):
+                continue
+            tx = self.flat.textures[int(ti)]
+            srgb = bool(tx["is_srgb"])
+            chain = self.mip_chain(int(ti))
+            if len(chain) == 1:
+                out[m] = self._bilinear(chain[0], srgb, uv[m])
+                continue
+            h, w = chain[0].shape[0], chain[0].shape[1]
+            g = grad[m].astype(np.float64)
+            rx = np.hypot(g[:, 0] * w, g[:, 1] * h)
+            ry = np.hypot(g[:, 2] * w, g[:, 3] * h)
+            major_x = rx >= ry
+            rmax, rmin = np.where(major_x, rx, ry), np.where(major_x, ry, rx)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                eta = np.where(rmin > 0, np.minimum(rmax / rmin, 4.0), np.where(rmax > 0, 4.0, 1.0))
+                eta = np.where(eta >= 1.0, eta, 1.0)
+                taps = np.ceil(eta).astype(np.int64)
+                lam = np.where(rmax / eta > 1.0, np.log2(np.maximum(rmax / eta, 1e-300)), 0.0)
+            lam = np.clip(np.nan_to_num(lam, nan=len(chain) - 1.0, posinf=len(chain) - 1.0), 0.0, len(chain) - 1.0)
+            hi = np.floor(lam).astype(np.int64)
+            lo = np.minimum(hi + 1, len(chain) - 1)
+            delta = (lam - hi)[:, None]
+            axis = np.where(major_x[:, None], g[:, 0:2], g[:, 2:4])
+            acc = np.zeros((m.size, 4), np.float64)
+            for i in range(1, 5):
+                live = np.nonzero(taps >= i)[0]
+                if live.size == 0:
+                    break
+                off = (i / (taps[live] + 1.0) - 0.5)[:, None]
+                tuv = (uv[m][live].astype(np.float64) + off * axis[live]).astype(F)
+                a, b = np.zeros((live.size, 4)), np.zeros((live.size, 4))
+                for lv in np.unique(np.concatenate([hi[live], lo[live]])):
+                    sel = hi[live] == lv
+                    if sel.any():
+                        a[sel] = self._bilinear(chain[lv], srgb, tuv[sel])
+                    sel = lo[live] == lv
+                    if sel.any():
+                        b[sel] = self._bilinear(chain[lv], srgb, tuv[sel])
+                acc[live] += a * (1.0 - delta[live]) + b * delta[live]
+            out[m] = (acc / taps[:, None]).astype(F)
         return out
 
     # -- raytrace.rchit:34-79: attribute fetch and interpolation ----------------------------------------------------------
@@ -227,18 +313,19 @@ class NpScene:
         return dict(world_pos=world_pos, world_nrm=world_nrm, world_tag=world_tag, world_bin=world_bin, uv=tex_coord,
                     mat=fl.materials[mat_index], inst=inst, i=(i0, i1, i2), b=(bx, by, bz))
 
-    def material_inputs(self, mat, uv):
-        """pbrGetBaseColor / pbrGetMetallicRoughness (gltf.glsl:26-45)"""
+    def material_inputs(self, mat, uv, grad=None):
+        """pbrGetBaseColor / pbrGetMetallicRoughness (gltf.glsl:26-45); grad: fragment-shader derivatives (G-buffer) or None"""
+        tex = (lambda ti, tuv, sel: self.texture(ti, tuv)) if grad is None else (lambda ti, tuv, sel: self.texture_grad(ti, tuv, grad[sel]))
         base = np.asarray(mat["pbrBaseColorFactor"], F)[:, :3].copy()
         bt = mat["pbrBaseColorTexture"].astype(np.int64)
         m = bt > -1
         if m.any():
-            base[m] = base[m] * self.texture(bt[m], uv[m])[:, :3]
+            base[m] = base[m] * tex(bt[m], uv[m], m)[:, :3]
         metal, rough = mat["metallicFactor"].astype(F).copy(), mat["roughnessFactor"].astype(F).copy()
         mt = mat["metallicRoughnessTexture"].astype(np.int64)
         m = mt > -1
         if m.any():
-            t = self.texture(mt[m], uv[m])
+            t = tex(mt[m], uv[m], m)
             rough[m] = rough[m] * t[:, 1]
             metal[m] = metal[m] * t[:, 2]
         return base.astype(F), metal, rough
@@ -376,9 +463,44 @@ def _half(x):
     return np.asarray(x, F).astype(np.float16).astype(F)  # rg16f render target (hello_vulkan.cpp:650-741), RNE
 
 
-def gbuffer_pixels(sc, clear_color, lights_count, view_inverse, proj_inverse, W, H, xs, ys):
+def _pixel_directions(view_inverse, proj_inverse, W, H, xs, ys):
+    n = xs.shape[0]
+    in_u = ((xs.astype(F) + F(0.5)) / F(W)).astype(F)
+    in_v = ((ys.astype(F) + F(0.5)) / F(H)).astype(F)
+    target = _mat4_vec4(proj_inverse, np.stack([in_u * F(2) - F(1), in_v * F(2) - F(1), np.ones(n, F), np.ones(n, F)], 1).astype(F))
+    return _mat4_vec4(view_inverse, np.concatenate([_normalize(target[:, :3]), np.zeros((n, 1), F)], 1))[:, :3]
+
+
+def _quad_derivatives(origin, corners, corner_uv, uv, view_inverse, proj_inverse, W, H, xs, ys):
+    """dFdx / dFdy of fragTexCoord: the other fragment of the pixel's 2x2 quad in x (y), run on the same primitive (a helper
+    invocation extrapolates the primitive's plane), minus this one, signed so the difference points to +x (+y).  float64."""
+    p0, p1, p2 = (c.astype(np.float64) for c in corners)
+    e1, e2 = p1 - p0, p2 - p0
+    nrm = np.cross(e1, e2)
+    o = origin.astype(np.float64)
+    out = np.zeros((xs.shape[0], 4), np.float64)
+    for k, (nx, ny, odd) in enumerate(((xs ^ 1, ys, xs & 1), (xs, ys ^ 1, ys & 1))):
+        d = _pixel_directions(view_inverse, proj_inverse, W, H, nx, ny).astype(np.float64)
+        denom = np.einsum("ij,ij->i", nrm, d)
+        ok = denom != 0
+        t = np.einsum("ij,ij->i", nrm, p0 - o) / np.where(ok, denom, 1.0)
+        q = o + d * t[:, None] - p0                            # point on the plane relative to p0; barycentrics by Cramer
+        a11, a12, a22 = (e1 * e1).sum(1), (e1 * e2).sum(1), (e2 * e2).sum(1)
+        b1, b2 = (q * e1).sum(1), (q * e2).sum(1)
+        det = a11 * a22 - a12 * a12
+        ok &= det != 0
+        det = np.where(ok, det, 1.0)
+        bu, bv = (b1 * a22 - b2 * a12) / det, (b2 * a11 - b1 * a12) / det
+        nuv = corner_uv[0] * (1 - bu - bv)[:, None] + corner_uv[1] * bu[:, None] + corner_uv[2] * bv[:, None]
+        diff = (nuv - uv.astype(np.float64)) * np.where(odd == 1, -1.0, 1.0)[:, None]
+        out[:, 2 * k: 2 * k + 2] = np.where(ok[:, None], diff, 0.0)
+    return out
+
+
+def gbuffer_pixels(sc, clear_color, lights_count, view_inverse, proj_inverse, W, H, xs, ys, mips=True):
     """The raster pass as a primary-ray cast through pixel centres: vert_shader.vert:60-74 per vertex, barycentric
-    interpolation, frag_shader.frag:96-214.  Returns dict of planes (N,4)/(N,2)."""
+    interpolation, frag_shader.frag:96-214.  mips: texture() takes its implicit LOD from the quad derivatives of fragTexCoord
+    (a fragment shader; False = LOD 0).  Returns dict of planes (N,4)/(N,2)."""
     xs, ys = np.asarray(xs, np.int64), np.asarray(ys, np.int64)
     n = xs.shape[0]
     color = np.tile(np.asarray(clear_color, F)[None, :], (n, 1))                  # main.cpp:483-487 clear values
@@ -386,10 +508,7 @@ def gbuffer_pixels(sc, clear_color, lights_count, view_inverse, proj_inverse, W,
     normal = np.tile(np.array([[0, 0, 0, 1]], F), (n, 1))
     rough = np.zeros((n, 2), F)
     origin = _mat4_vec4(view_inverse, np.tile(np.array([[0, 0, 0, 1]], F), (n, 1)))[:, :3]
-    in_u = ((xs.astype(F) + F(0.5)) / F(W)).astype(F)
-    in_v = ((ys.astype(F) + F(0.5)) / F(H)).astype(F)
-    target = _mat4_vec4(proj_inverse, np.stack([in_u * F(2) - F(1), in_v * F(2) - F(1), np.ones(n, F), np.ones(n, F)], 1).astype(F))
-    direction = _mat4_vec4(view_inverse, np.concatenate([_normalize(target[:, :3]), np.zeros((n, 1), F)], 1))[:, :3]
+    direction = _pixel_directions(view_inverse, proj_inverse, W, H, xs, ys)
     t, u, v, tri = sc.closest(origin, direction)
     h = np.nonzero(tri >= 0)[0]
     if h.size == 0:
@@ -399,9 +518,13 @@ def gbuffer_pixels(sc, clear_color, lights_count, view_inverse, proj_inverse, W,
     P, N_, T4 = np.asarray(fl.positions, F).reshape(-1, 3), np.asarray(fl.normals, F).reshape(-1, 3), np.asarray(fl.tangents, F).reshape(-1, 4)
     o2w, w2o = sc.o2w[A["inst"]], sc.w2o[A["inst"]]
     w_pos = np.zeros((h.size, 3), F); w_nrm = np.zeros((h.size, 3), F); w_tag = np.zeros((h.size, 3), F); w_bin = np.zeros((h.size, 3), F)
+    corners, corner_uv = [], []
+    UV = np.asarray(fl.texcoords0, F).reshape(-1, 2)
     for i, b in zip(A["i"], A["b"]):                                              # vert_shader.vert:62-72 at each of the three vertices
         p = P[i]
         wp = (((o2w[:, :, 0] * p[:, 0:1] + o2w[:, :, 1] * p[:, 1:2]) + o2w[:, :, 2] * p[:, 2:3]) + o2w[:, :, 3]).astype(F)
+        corners.append(wp)
+        corner_uv.append(UV[i].astype(np.float64))
 
         def it(nv):  # mat3(inverseTransposeMatrix) * n
             return ((nv[:, 0:1] * w2o[:, 0, :] + nv[:, 1:2] * w2o[:, 1, :]) + nv[:, 2:3] * w2o[:, 2, :]).astype(F)
@@ -412,6 +535,8 @@ def gbuffer_pixels(sc, clear_color, lights_count, view_inverse, proj_inverse, W,
         wb = (_cross(wn, wt) * T4[i, 3][:, None]).astype(F)
         w_pos, w_nrm, w_tag, w_bin = w_pos + wp * b, w_nrm + wn * b, w_tag + wt * b, w_bin + wb * b
     mat, uv = A["mat"], A["uv"]
+    grad = _quad_derivatives(origin[h], corners, corner_uv, uv, view_inverse, proj_inverse, W, H, xs[h], ys[h]) if mips else None
+    tex = (lambda ti, sel: sc.texture(ti, uv[sel])) if grad is None else (lambda ti, sel: sc.texture_grad(ti, uv[sel], grad[sel]))
     view_dir = (w_pos - origin[h]).astype(F)
     N = _normalize(w_nrm)                                                         # frag_shader.frag:96-119
     nt = mat["normalTexture"].astype(np.int64)
@@ -420,16 +545,16 @@ def gbuffer_pixels(sc, clear_color, lights_count, view_inverse, proj_inverse, W,
         T = _normalize(w_tag[m]); B = _normalize(w_bin[m]); Nm = N[m]
         T = _normalize(T - _dot(T, Nm)[:, None] * Nm)
         B = _normalize(B - _dot(B, Nm)[:, None] * Nm - _dot(B, T)[:, None] * T)
-        nrm = _normalize(sc.texture(nt[m], uv[m])[:, :3] * F(2.0) - F(1.0))
+        nrm = _normalize(tex(nt[m], m)[:, :3] * F(2.0) - F(1.0))
         N[m] = _normalize(T * nrm[:, 0:1] + B * nrm[:, 1:2] + Nm * nrm[:, 2:3])
-    base, metal, rough_v = sc.material_inputs(mat, uv)
+    base, metal, rough_v = sc.material_inputs(mat, uv, grad)
     albedo = ((F(1.0) - metal)[:, None] * base).astype(F)
     V = _normalize(-view_dir)
     emit = np.asarray(mat["emissiveFactor"], F).copy()
     et = mat["emissiveTexture"].astype(np.int64)
     m = et > -1
     if m.any():
-        emit[m] = emit[m] * sc.texture(et[m], uv[m])[:, :3]
+        emit[m] = emit[m] * tex(et[m], m)[:, :3]
     col = np.zeros((h.size, 3), F)
     for li in range(lights_count):                                               # frag_shader.frag:193-213
         lt = fl.lights[li]

@@ -177,11 +177,17 @@ struct Tri  // world-space triangle for traversal
   V3 v0, e1, e2;
   uint32_t gid, inst, prim;
 };
+struct TexLevel
+{
+  uint32_t w, h;
+  std::vector<uint8_t> rgba;
+};
 struct Tex
 {
   uint32_t w, h;
   std::vector<uint8_t> rgba;
   bool srgb;
+  std::vector<TexLevel> mips;  // mips[0] unused (level 0 is rgba); levels 1.. as nvvk::cmdGenerateMipmaps blits them (hello_vulkan.cpp:499)
 };
 struct Aabb
 {
@@ -223,6 +229,7 @@ struct orc_scene
   std::vector<Instance> inst;
   std::vector<Tex> tex;
   float srgb_lut[256];
+  int gbufferMips = 1;  // hybrid G-buffer samples with implicit LOD (fragment shader semantics); 0 = LOD 0
   std::vector<Tri> tris;  // flattened, gid order
   // BVH
   std::vector<BvhNode> nodes;
@@ -596,31 +603,30 @@ inline int wrapi(int i, int n)
   int m = i % n;
   return m < 0 ? m + n : m;
 }
-inline V4 texel(const orc_scene& s, const Tex& tx, int x, int y)
+inline V4 texelOf(const orc_scene& s, bool srgb, const uint8_t* rgba, uint32_t w, int x, int y)
 {
-  const uint8_t* p = &tx.rgba[((size_t)y * tx.w + x) * 4];
+  const uint8_t* p = &rgba[((size_t)y * w + x) * 4];
   V4 r;
-  if(tx.srgb) { r.x = s.srgb_lut[p[0]]; r.y = s.srgb_lut[p[1]]; r.z = s.srgb_lut[p[2]]; }
+  if(srgb) { r.x = s.srgb_lut[p[0]]; r.y = s.srgb_lut[p[1]]; r.z = s.srgb_lut[p[2]]; }
   else { r.x = (float)p[0] / 255.0f; r.y = (float)p[1] / 255.0f; r.z = (float)p[2] / 255.0f; }
   r.w = (float)p[3] / 255.0f;
   return r;
 }
-V4 sampleTex(const orc_scene& s, int texIndex, float u, float v, Counters& c)
+// one bilinear REPEAT tap in one level of a texture
+V4 sampleLevel(const orc_scene& s, const Tex& tx, uint32_t level, float u, float v)
 {
-  c.tex_taps++;
-  if(s.tex.empty() || texIndex < 0 || texIndex >= (int)s.tex.size())
-    return V4{1, 1, 1, 1};  // 1x1 white dummy (hello_vulkan.cpp:468-472)
-  const Tex& tx = s.tex[texIndex];
-  float fx = u * (float)tx.w - 0.5f;
-  float fy = v * (float)tx.h - 0.5f;
+  const uint32_t w = level ? tx.mips[level].w : tx.w, h = level ? tx.mips[level].h : tx.h;
+  const uint8_t* data = level ? tx.mips[level].rgba.data() : tx.rgba.data();
+  float fx = u * (float)w - 0.5f;
+  float fy = v * (float)h - 0.5f;
   if(!(fabsf(fx) < 1.0e9f)) fx = 0.0f;
   if(!(fabsf(fy) < 1.0e9f)) fy = 0.0f;
   float flx = floorf(fx), fly = floorf(fy);
   float ax = fx - flx, ay = fy - fly;
-  int x0 = wrapi((int)flx, (int)tx.w), x1 = wrapi((int)flx + 1, (int)tx.w);
-  int y0 = wrapi((int)fly, (int)tx.h), y1 = wrapi((int)fly + 1, (int)tx.h);
-  V4 t00 = texel(s, tx, x0, y0), t10 = texel(s, tx, x1, y0);
-  V4 t01 = texel(s, tx, x0, y1), t11 = texel(s, tx, x1, y1);
+  int x0 = wrapi((int)flx, (int)w), x1 = wrapi((int)flx + 1, (int)w);
+  int y0 = wrapi((int)fly, (int)h), y1 = wrapi((int)fly + 1, (int)h);
+  V4 t00 = texelOf(s, tx.srgb, data, w, x0, y0), t10 = texelOf(s, tx.srgb, data, w, x1, y0);
+  V4 t01 = texelOf(s, tx.srgb, data, w, x0, y1), t11 = texelOf(s, tx.srgb, data, w, x1, y1);
   float bx = 1.0f - ax, by = 1.0f - ay;
   V4 r;
   r.x = (t00.x * bx + t10.x * ax) * by + (t01.x * bx + t11.x * ax) * ay;
@@ -628,6 +634,135 @@ V4 sampleTex(const orc_scene& s, int texIndex, float u, float v, Counters& c)
   r.z = (t00.z * bx + t10.z * ax) * by + (t01.z * bx + t11.z * ax) * ay;
   r.w = (t00.w * bx + t10.w * ax) * by + (t01.w * bx + t11.w * ax) * ay;
   return r;
+}
+V4 sampleTex(const orc_scene& s, int texIndex, float u, float v, Counters& c)
+{
+  c.tex_taps++;
+  if(s.tex.empty() || texIndex < 0 || texIndex >= (int)s.tex.size())
+    return V4{1, 1, 1, 1};  // 1x1 white dummy (hello_vulkan.cpp:468-472)
+  return sampleLevel(s, s.tex[texIndex], 0, u, v);
+}
+
+// ---- implicit-LOD texture() of the fragment shader (hybrid G-buffer only) ------------------------------------------------
+// The sampler of hello_vulkan.cpp:448-454: linear min / mag / mip filters over the whole chain (maxLod = FLT_MAX), anisotropy
+// enabled with maxAnisotropy 4.  Restated from the Vulkan 1.3 specification, chapter "Image Operations" (Scale Factor
+// Operation, LOD Operation, Texel Anisotropic Filtering): the exact LOD and tap placement of a GPU are implementation
+// defined inside the bounds the spec gives, so this pins OUR definition (shared with the HIP sampler), not NVIDIA's.
+struct TexGrad
+{
+  float dudx, dvdx, dudy, dvdy;  // dFdx / dFdy of the normalised texture coordinates
+};
+// log2 by exponent extraction and the atanh series (same operation sequence as the device: no libm call on either side)
+inline float lodLog2(float x)
+{
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  int e = (int)((b >> 23) & 255u) - 127;
+  const uint32_t mb = (b & 0x007fffffu) | 0x3f800000u;
+  float m;
+  memcpy(&m, &mb, 4);
+  if(m > 1.41421356f)
+  {
+    m = m * 0.5f;
+    e += 1;
+  }
+  const float q = (m - 1.0f) / (m + 1.0f), q2 = q * q;
+  const float series = 1.0f + q2 * (0.333333333f + q2 * (0.2f + q2 * (0.142857143f + q2 * 0.111111111f)));
+  return (float)e + (2.0f * q * series) * 1.44269504f;
+}
+V4 sampleTexGrad(const orc_scene& s, int texIndex, float u, float v, const TexGrad& g, Counters& c)
+{
+  c.tex_taps++;
+  if(s.tex.empty() || texIndex < 0 || texIndex >= (int)s.tex.size())
+    return V4{1, 1, 1, 1};
+  const Tex& tx = s.tex[texIndex];
+  const uint32_t levels = (uint32_t)tx.mips.size();
+  if(levels <= 1u)
+    return sampleLevel(s, tx, 0, u, v);
+  // scale factors in texel units of level 0
+  const float fw = (float)tx.w, fh = (float)tx.h;
+  const float mxu = g.dudx * fw, mxv = g.dvdx * fh, myu = g.dudy * fw, myv = g.dvdy * fh;
+  const float rx2 = mxu * mxu + mxv * mxv, ry2 = myu * myu + myv * myv;
+  const bool majorX = rx2 >= ry2;
+  const float rmax = sqrtf(majorX ? rx2 : ry2), rmin = sqrtf(majorX ? ry2 : rx2);
+  float eta = 1.0f;  // anisotropy ratio, at most maxAnisotropy = 4
+  if(rmin > 0.0f)
+    eta = glsl_min(rmax / rmin, 4.0f);
+  else if(rmax > 0.0f)
+    eta = 4.0f;
+  if(!(eta >= 1.0f))
+    eta = 1.0f;
+  const int N = (int)ceilf(eta);
+  const float scale = rmax / eta;
+  float lambda = 0.0f;
+  if(scale > 1.0f && scale < 3.0e38f)
+    lambda = lodLog2(scale);
+  else if(!(scale <= 1.0f))
+    lambda = (float)(levels - 1u);
+  lambda = glsl_clamp(lambda, 0.0f, (float)(levels - 1u));
+  const float fl = floorf(lambda), delta = lambda - fl;
+  const uint32_t hi = (uint32_t)fl, lo = std::min(hi + 1u, levels - 1u);
+  const float du = majorX ? g.dudx : g.dudy, dv = majorX ? g.dvdx : g.dvdy;
+  V4 r{0, 0, 0, 0};
+  for(int i = 1; i <= N; i++)
+  {
+    const float o = (float)i / (float)(N + 1) - 0.5f;
+    float tu = u + o * du, tv = v + o * dv;
+    if(!(fabsf(tu) < 1.0e9f) || !(fabsf(tv) < 1.0e9f))
+    {
+      tu = u;
+      tv = v;
+    }
+    const V4 a = sampleLevel(s, tx, hi, tu, tv), b = sampleLevel(s, tx, lo, tu, tv);
+    r.x = r.x + (a.x * (1.0f - delta) + b.x * delta);
+    r.y = r.y + (a.y * (1.0f - delta) + b.y * delta);
+    r.z = r.z + (a.z * (1.0f - delta) + b.z * delta);
+    r.w = r.w + (a.w * (1.0f - delta) + b.w * delta);
+  }
+  const float inv = 1.0f / (float)N;
+  r.x = r.x * inv; r.y = r.y * inv; r.z = r.z * inv; r.w = r.w * inv;
+  return r;
+}
+
+// vkCmdBlitImage with VK_FILTER_LINEAR from level L - 1 to level L (what nvvk::cmdGenerateMipmaps records per level): the
+// destination texel centre maps to ((x + 0.5) * srcW / dstW, ...) in the source, bilinear around it with clamp-to-edge; an sRGB
+// image is filtered on its decoded values and re-encoded.  For even sizes this is the 2x2 box filter.
+inline float srgbEncode(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
+void buildMipChain(const orc_scene& s, Tex& tx)
+{
+  tx.mips.clear();
+  tx.mips.push_back(TexLevel{tx.w, tx.h, {}});
+  uint32_t w = tx.w, h = tx.h;
+  const uint8_t* src = tx.rgba.data();
+  while(w > 1 || h > 1)
+  {
+    TexLevel L;
+    L.w = std::max(1u, w / 2); L.h = std::max(1u, h / 2);
+    L.rgba.resize((size_t)L.w * L.h * 4);
+    for(uint32_t y = 0; y < L.h; y++)
+      for(uint32_t x = 0; x < L.w; x++)
+      {
+        const float fu = ((float)x + 0.5f) * ((float)w / (float)L.w) - 0.5f, fv = ((float)y + 0.5f) * ((float)h / (float)L.h) - 0.5f;
+        const float flx = floorf(fu), fly = floorf(fv), ax = fu - flx, ay = fv - fly;
+        const int x0 = std::clamp((int)flx, 0, (int)w - 1), x1 = std::clamp((int)flx + 1, 0, (int)w - 1);
+        const int y0 = std::clamp((int)fly, 0, (int)h - 1), y1 = std::clamp((int)fly + 1, 0, (int)h - 1);
+        const V4 t00 = texelOf(s, tx.srgb, src, w, x0, y0), t10 = texelOf(s, tx.srgb, src, w, x1, y0);
+        const V4 t01 = texelOf(s, tx.srgb, src, w, x0, y1), t11 = texelOf(s, tx.srgb, src, w, x1, y1);
+        const float c00[4] = {t00.x, t00.y, t00.z, t00.w}, c10[4] = {t10.x, t10.y, t10.z, t10.w};
+        const float c01[4] = {t01.x, t01.y, t01.z, t01.w}, c11[4] = {t11.x, t11.y, t11.z, t11.w};
+        for(int k = 0; k < 4; k++)
+        {
+          float val = (c00[k] * (1.0f - ax) + c10[k] * ax) * (1.0f - ay) + (c01[k] * (1.0f - ax) + c11[k] * ax) * ay;
+          if(tx.srgb && k < 3)
+            val = srgbEncode(val);
+          val = val < 0.0f ? 0.0f : (val > 1.0f ? 1.0f : val);
+          L.rgba[((size_t)y * L.w + x) * 4 + k] = (uint8_t)(val * 255.0f + 0.5f);
+        }
+      }
+    w = L.w; h = L.h;
+    tx.mips.push_back(std::move(L));
+    src = tx.mips.back().rgba.data();
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -637,7 +772,12 @@ struct ShadeCtx
 {
   const orc_scene& s;
   Counters& c;
+  const TexGrad* grad = nullptr;  // non-NULL: fragment-shader texture() with these derivatives (hybrid G-buffer); NULL: LOD 0 (ray tracing stages)
 };
+inline V4 sampleTex(ShadeCtx& cx, int texIndex, float u, float v)
+{
+  return cx.grad ? sampleTexGrad(cx.s, texIndex, u, v, *cx.grad, cx.c) : sampleTex(cx.s, texIndex, u, v, cx.c);
+}
 inline V3 matBase(const GltfPBRMaterial& m) { return v3(m.pbrBaseColorFactor[0], m.pbrBaseColorFactor[1], m.pbrBaseColorFactor[2]); }
 // gltf.glsl:26-32
 V3 pbrGetBaseColor(ShadeCtx& cx, const GltfPBRMaterial& mat, float tu, float tv)
@@ -645,7 +785,7 @@ V3 pbrGetBaseColor(ShadeCtx& cx, const GltfPBRMaterial& mat, float tu, float tv)
   V3 color = matBase(mat);
   if(mat.pbrBaseColorTexture > -1)
   {
-    V4 t = sampleTex(cx.s, mat.pbrBaseColorTexture, tu, tv, cx.c);
+    V4 t = sampleTex(cx, mat.pbrBaseColorTexture, tu, tv);
     color = color * v3(t.x, t.y, t.z);
   }
   return color;
@@ -657,7 +797,7 @@ void pbrGetMetallicRoughness(ShadeCtx& cx, const GltfPBRMaterial& mat, float tu,
   roughness = mat.roughnessFactor;
   if(mat.metallicRoughnessTexture > -1)
   {
-    V4 t = sampleTex(cx.s, mat.metallicRoughnessTexture, tu, tv, cx.c);
+    V4 t = sampleTex(cx, mat.metallicRoughnessTexture, tu, tv);
     roughness *= t.y;
     metallic *= t.z;
   }
@@ -1080,6 +1220,38 @@ inline void nrdPackNormalRoughness(V3 N, float roughness, float materialID, floa
   out[3] = quantizeUnorm(glsl_clamp(materialID / 3.0f, 0.0f, 1.0f), 3.0f);
 }
 
+// direction of the primary ray through the centre of pixel (x, y) (raytrace.rgen:46-51 with jitter 0.5)
+V3 pixelCentreDir(const GlobalUniforms& uni, uint32_t x, uint32_t y, uint32_t W, uint32_t H)
+{
+  const float inU = ((float)x + 0.5f) / (float)W, inV = ((float)y + 0.5f) / (float)H;
+  const float d4[4] = {inU * 2.0f - 1.0f, inV * 2.0f - 1.0f, 1, 1};
+  float target[4];
+  mat4MulVec4(uni.projInverse, d4, target);
+  const V3 tn = normalize(v3(target[0], target[1], target[2]));
+  const float t4[4] = {tn.x, tn.y, tn.z, 0};
+  float direction[4];
+  mat4MulVec4(uni.viewInverse, t4, direction);
+  return v3(direction[0], direction[1], direction[2]);
+}
+// fragTexCoord of a (helper) fragment at another pixel of the same primitive: the rasteriser's perspective-correct
+// interpolation is the barycentric position where that pixel's view ray meets the triangle's plane.
+bool texCoordOnPlane(V3 org, V3 dir, const V3 p[3], const float tcU[3], const float tcV[3], float& u, float& v)
+{
+  const V3 e1 = p[1] - p[0], e2 = p[2] - p[0];
+  const V3 pvec = cross(dir, e2);
+  const float det = dot(e1, pvec);
+  if(det == 0.0f)
+    return false;
+  const V3 tvec = org - p[0];
+  const float bu = dot(tvec, pvec) / det;
+  const V3 qvec = cross(tvec, e1);
+  const float bv = dot(dir, qvec) / det;
+  const float b0 = 1.0f - bu - bv;
+  u = tcU[0] * b0 + tcU[1] * bu + tcU[2] * bv;
+  v = tcV[0] * b0 + tcV[1] * bu + tcV[2] * bv;
+  return true;
+}
+
 // vert_shader.vert:60-74 per vertex, barycentric interpolation (what the rasteriser does), frag_shader.frag:122-214
 void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount, const GlobalUniforms& uni, uint32_t x, uint32_t y, uint32_t W,
                   uint32_t H, bool useBvh, GbufPixel& out, Counters& c, const float* viewMatrix = nullptr)
@@ -1117,10 +1289,13 @@ void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount
   const float bw[3] = {1.0f - h.u - h.v, h.u, h.v};
   V3 wPos = v3(0.0f), wNrm = v3(0.0f), wTag = v3(0.0f), wBin = v3(0.0f);
   float tu = 0.0f, tv = 0.0f;
+  V3 corner[3];
+  float cornerU[3], cornerV[3];
   for(int k = 0; k < 3; k++)
   {
     const uint32_t i = vi[k];
     const V3 p = xformPoint(in, s.pos[i]);                       // modelMatrix * position
+    corner[k] = p; cornerU[k] = s.uv2[2 * i]; cornerV[k] = s.uv2[2 * i + 1];
     const V3 n = normalize(xformNormal(in, s.nrm[i]));           // mat3(inverseTranspose) * normal
     V3 t = normalize(xformNormal(in, v3(s.tan4[4 * i], s.tan4[4 * i + 1], s.tan4[4 * i + 2])));
     t = normalize(t - dot(t, n) * n);
@@ -1128,6 +1303,24 @@ void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount
     wPos = wPos + p * bw[k]; wNrm = wNrm + n * bw[k]; wTag = wTag + t * bw[k]; wBin = wBin + b * bw[k];
     tu = tu + s.uv2[2 * i] * bw[k];
     tv = tv + s.uv2[2 * i + 1] * bw[k];
+  }
+  // Implicit derivatives of fragTexCoord for texture(): dFdx / dFdy are differences between the two fragments of the pixel's
+  // 2x2 quad in that direction (Vulkan spec, "Derivative Operations"); the quad neighbour runs on the same primitive.
+  TexGrad grad{0.0f, 0.0f, 0.0f, 0.0f};
+  if(s.gbufferMips)
+  {
+    float nu, nv;
+    if(texCoordOnPlane(org, pixelCentreDir(uni, x ^ 1u, y, W, H), corner, cornerU, cornerV, nu, nv))
+    {
+      const float sgn = (x & 1u) ? -1.0f : 1.0f;
+      grad.dudx = (nu - tu) * sgn; grad.dvdx = (nv - tv) * sgn;
+    }
+    if(texCoordOnPlane(org, pixelCentreDir(uni, x, y ^ 1u, W, H), corner, cornerU, cornerV, nu, nv))
+    {
+      const float sgn = (y & 1u) ? -1.0f : 1.0f;
+      grad.dudy = (nu - tu) * sgn; grad.dvdy = (nv - tv) * sgn;
+    }
+    cx.grad = &grad;
   }
   const V3 viewDir = wPos - org;
   // frag_shader.frag:96-119 getNormal
@@ -1137,7 +1330,7 @@ void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount
     V3 T = normalize(wTag), B = normalize(wBin);
     T = normalize(T - dot(T, N) * N);
     B = normalize(B - dot(B, N) * N - dot(B, T) * T);
-    const V4 tx = sampleTex(s, mat.normalTexture, tu, tv, c);
+    const V4 tx = sampleTex(cx, mat.normalTexture, tu, tv);
     V3 nrm = v3(tx.x, tx.y, tx.z) * 2.0f - v3(1.0f);
     nrm = normalize(nrm);
     nrm = normalize(T * nrm.x + B * nrm.y + N * nrm.z);
@@ -1152,7 +1345,7 @@ void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount
   V3 emittance = v3(mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]);
   if(mat.emissiveTexture > -1)
   {
-    const V4 tx = sampleTex(s, mat.emissiveTexture, tu, tv, c);
+    const V4 tx = sampleTex(cx, mat.emissiveTexture, tu, tv);
     emittance = emittance * v3(tx.x, tx.y, tx.z);
   }
   for(int i = 0; i < lightsCount; i++)  // frag_shader.frag:193-213 (every light, no shadow test)
@@ -1376,6 +1569,7 @@ orc_scene* orc_scene_create(const vkrt_scene_desc* d)
     Tex tx;
     tx.w = d->textures[t].width; tx.h = d->textures[t].height; tx.srgb = d->textures[t].is_srgb != 0;
     tx.rgba.assign(d->textures[t].rgba8, d->textures[t].rgba8 + (size_t)tx.w * tx.h * 4);
+    buildMipChain(*s, tx);
     s->tex.push_back(std::move(tx));
   }
   uint32_t gid = 0;
@@ -1766,6 +1960,32 @@ void orc_post(int rtMode, int viewAccumulated, int useGI, uint32_t n, const floa
 }
 
 float orc_quantize_half(float f) { return quantizeHalf(f); }
+
+/* 1 (default): the G-buffer's texture() uses implicit LOD + anisotropy; 0: LOD 0 (what the numpy restatement implements). */
+void orc_set_gbuffer_mips(orc_scene* s, int on) { s->gbufferMips = on ? 1 : 0; }
+
+/* Mip chain introspection: number of levels; size and RGBA8 texels of one level (rgba8 may be NULL to query the size). */
+uint32_t orc_texture_levels(const orc_scene* s, int texIndex) { return (uint32_t)s->tex[(size_t)texIndex].mips.size(); }
+void orc_texture_level(const orc_scene* s, int texIndex, uint32_t level, uint32_t* w, uint32_t* h, uint8_t* rgba8)
+{
+  const Tex& tx = s->tex[(size_t)texIndex];
+  const uint32_t lw = level ? tx.mips[level].w : tx.w, lh = level ? tx.mips[level].h : tx.h;
+  if(w) *w = lw;
+  if(h) *h = lh;
+  if(rgba8)
+    memcpy(rgba8, level ? tx.mips[level].rgba.data() : tx.rgba.data(), (size_t)lw * lh * 4);
+}
+/* Implicit-LOD sampler spot check: uv = float[2n], grads = float[4n] (dudx, dvdx, dudy, dvdy) -> rgba float[4n]. */
+void orc_sample_texture_grad(const orc_scene* s, int texIndex, uint32_t n, const float* uv, const float* grads, float* rgba)
+{
+  Counters c;
+  for(uint32_t i = 0; i < n; i++)
+  {
+    const TexGrad g{grads[4 * i], grads[4 * i + 1], grads[4 * i + 2], grads[4 * i + 3]};
+    V4 r = sampleTexGrad(*s, texIndex, uv[2 * i], uv[2 * i + 1], g, c);
+    rgba[4 * i] = r.x; rgba[4 * i + 1] = r.y; rgba[4 * i + 2] = r.z; rgba[4 * i + 3] = r.w;
+  }
+}
 
 /* Bilinear sampler spot check: uv = float[2n] -> rgba float[4n] from texture texIndex. */
 void orc_sample_texture(const orc_scene* s, int texIndex, uint32_t n, const float* uv, float* rgba)

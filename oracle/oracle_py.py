@@ -66,6 +66,11 @@ def lib():
         L.orc_quantize_half.argtypes = [C.c_float]
         L.orc_quantize_half.restype = C.c_float
         L.orc_sample_texture.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_sample_texture_grad.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_gbuffer_mips.argtypes = [C.c_void_p, C.c_int]
+        L.orc_texture_levels.argtypes = [C.c_void_p, C.c_int]
+        L.orc_texture_levels.restype = C.c_uint32
+        L.orc_texture_level.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -199,6 +204,29 @@ class OracleScene:
         uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         out = np.zeros((uv.shape[0], 4), np.float32)
         lib().orc_sample_texture(self._h, tex_index, uv.shape[0], uv.ctypes.data, out.ctypes.data)
+        return out
+
+    def sample_texture_grad(self, tex_index, uv, grads):
+        """texture() with explicit derivatives (dudx, dvdx, dudy, dvdy per sample): trilinear + anisotropy 4."""
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        grads = np.ascontiguousarray(grads, np.float32).reshape(-1, 4)
+        assert grads.shape[0] == uv.shape[0]
+        out = np.zeros((uv.shape[0], 4), np.float32)
+        lib().orc_sample_texture_grad(self._h, tex_index, uv.shape[0], uv.ctypes.data, grads.ctypes.data, out.ctypes.data)
+        return out
+
+    def set_gbuffer_mips(self, on):
+        lib().orc_set_gbuffer_mips(self._h, 1 if on else 0)
+
+    def texture_levels(self, tex_index):
+        """The mip chain of one texture as a list of (h, w, 4) uint8 arrays (level 0 first)."""
+        out = []
+        for level in range(lib().orc_texture_levels(self._h, tex_index)):
+            w, h = C.c_uint32(), C.c_uint32()
+            lib().orc_texture_level(self._h, tex_index, level, C.byref(w), C.byref(h), None)
+            px = np.zeros((h.value, w.value, 4), np.uint8)
+            lib().orc_texture_level(self._h, tex_index, level, None, None, px.ctypes.data)
+            out.append(px)
         return out
 
 

@@ -46,11 +46,12 @@ struct DevMaterial
 };
 static_assert(sizeof(DevMaterial) == 128, "DevMaterial");
 
+#define VKRT_MAX_MIPS 16
 struct DevTexture
 {
-  uint32_t offset;  // first texel in the RGBA8 pool
+  uint32_t offset;  // first texel of level 0 in the RGBA8 pool
   uint32_t width, height;
-  uint32_t srgb;
+  uint32_t srgb;    // bit 0: sRGB; bits 8..: number of mip levels (>= 1); level offsets in DevScene::texMips
 };
 
 // BVH2 node, 64 bytes = 4 x float4 (one 64-B line, four dwordx4 loads):
@@ -75,7 +76,8 @@ struct DevScene
   const GltfLight* lights;
   const DevInstance* instances;
   const DevTexture* textures;
-  const uint32_t* texels;     // RGBA8 pool
+  const uint32_t* texMips;    // [textureCount][VKRT_MAX_MIPS]: first texel of every mip level (hello_vulkan.cpp:496 cmdGenerateMipmaps)
+  const uint32_t* texels;     // RGBA8 pool (all levels)
   const float* srgbLut;       // 512 floats: [0,256) sRGB decode of i/255, [256,512) i/255 (UNORM decode)
   const float4* nodes;
   const float4* tris;
@@ -89,6 +91,7 @@ struct DevScene
   uint32_t triThreshold;      // wide8: lanes with pending triangles needed before a wave tests them (0 = test at once)
   uint32_t sharePeriodMask;   // work sharing is attempted on steps with (step & mask) == mask (0 = every step)
   uint32_t shareMinIdle;      // wide8, wavefront mode: idle lanes of a wave take over pending subtrees of busy lanes once this many are idle (0 = off)
+  uint32_t gbufferMips;       // hybrid G-buffer: 1 = implicit-LOD texture() as in a fragment shader (trilinear + 4x anisotropy), 0 = LOD 0
   uint32_t shareFlags;        // bit 0: lanes whose stack is empty also donate the farthest pending child of their current group
   unsigned long long* faults; // sticky tally of dropped stack pushes + step-limit exits (a walk that was cut short); must stay 0
 };

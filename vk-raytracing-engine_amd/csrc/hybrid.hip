@@ -83,6 +83,35 @@ VKRT_DEV float4 nrdPackNormalRoughness(f3 N, float roughness, float materialID) 
                      quantizeUnorm(glsl_clamp(materialID / 3.0f, 0.0f, 1.0f), 3.0f));
 }
 
+// Primary-ray direction of pixel (x, y), raytraceHybrid.rgen / the rasteriser's view of the same pixel centre
+VKRT_DEV f3 primaryDir(const TraceParams& P, uint32_t x, uint32_t y)
+{
+  float target[4], direction[4];
+  const float inU = ((float)x + 0.5f) / (float)P.fullW, inV = ((float)y + 0.5f) / (float)P.fullH;
+  mat4MulVec4(P.projInverse, inU * 2.0f - 1.0f, inV * 2.0f - 1.0f, 1.0f, 1.0f, target);
+  const f3 tn = normalize3(mk3(target[0], target[1], target[2]));
+  mat4MulVec4(P.viewInverse, tn.x, tn.y, tn.z, 0.0f, direction);
+  return mk3(direction[0], direction[1], direction[2]);
+}
+// Texture coordinates where the ray (org, dir) meets the plane of the triangle (p0, p1, p2): what the rasteriser's
+// perspective-correct interpolation evaluates for a (helper) fragment of the same primitive.  false: ray parallel to the plane.
+VKRT_DEV bool planeTexCoord(f3 org, f3 dir, f3 p0, f3 p1, f3 p2, const float* tcu, const float* tcv, float& u, float& v)
+{
+  const f3 e1 = p1 - p0, e2 = p2 - p0;
+  const f3 pvec = cross3(dir, e2);
+  const float det = dot3(e1, pvec);
+  if(det == 0.0f)
+    return false;
+  const f3 tvec = org - p0;
+  const float bu = dot3(tvec, pvec) / det;
+  const f3 qvec = cross3(tvec, e1);
+  const float bv = dot3(dir, qvec) / det;
+  const float b0 = 1.0f - bu - bv;
+  u = tcu[0] * b0 + tcu[1] * bu + tcu[2] * bv;
+  v = tcv[0] * b0 + tcv[1] * bu + tcv[2] * bv;
+  return true;
+}
+
 VKRT_DEV bool pixelOf(const TraceParams& P, uint32_t& x, uint32_t& y, uint32_t& lrow)
 {
   const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;  // tile-major, as in the path tracer
@@ -118,13 +147,9 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
     float2 oRough = make_float2(0.0f, 0.0f);
     float4 oNormRough = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // main.cpp:488-491 clear values
     float oViewZ = 0.0f;
-    float origin[4], target[4], direction[4];
+    float origin[4];
     mat4MulVec4(P.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f, origin);
-    const float inU = ((float)x + 0.5f) / (float)P.fullW, inV = ((float)y + 0.5f) / (float)P.fullH;
-    mat4MulVec4(P.projInverse, inU * 2.0f - 1.0f, inV * 2.0f - 1.0f, 1.0f, 1.0f, target);
-    const f3 tn = normalize3(mk3(target[0], target[1], target[2]));
-    mat4MulVec4(P.viewInverse, tn.x, tn.y, tn.z, 0.0f, direction);
-    const f3 org = mk3(origin[0], origin[1], origin[2]), dir = mk3(direction[0], direction[1], direction[2]);
+    const f3 org = mk3(origin[0], origin[1], origin[2]), dir = primaryDir(P, x, y);
     RayHit hit;
     nClosest = 1;
     traverse_any<false, WIDE>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
@@ -145,6 +170,8 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
       const float bw[3] = {1.0f - hit.u - hit.v, hit.u, hit.v};
       f3 wPos = mk3(0.0f), wNrm = mk3(0.0f), wTag = mk3(0.0f), wBin = mk3(0.0f);
       float tu = 0.0f, tv = 0.0f;
+      f3 cornerPos[3];
+      float cornerU[3], cornerV[3];
 #pragma unroll
       for(int k = 0; k < 3; k++)  // vert_shader.vert:60-74 per vertex, then the rasteriser's barycentric interpolation
       {
@@ -158,6 +185,26 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
         wPos = wPos + pw * bw[k]; wNrm = wNrm + n * bw[k]; wTag = wTag + t * bw[k]; wBin = wBin + bn * bw[k];
         tu = tu + b.z * bw[k];
         tv = tv + b.w * bw[k];
+        cornerPos[k] = pw; cornerU[k] = b.z; cornerV[k] = b.w;
+      }
+      // dFdx / dFdy of fragTexCoord: differences inside the pixel's 2x2 quad (the neighbour is the other pixel of the quad in
+      // that direction, evaluated on this primitive's plane like a helper invocation), Vulkan spec "Derivative Operations"
+      TexGrad grad;
+      grad.on = sc.gbufferMips != 0u;
+      grad.dudx = grad.dvdx = grad.dudy = grad.dvdy = 0.0f;
+      if(grad.on)
+      {
+        float nu, nv;
+        if(planeTexCoord(org, primaryDir(P, x ^ 1u, y), cornerPos[0], cornerPos[1], cornerPos[2], cornerU, cornerV, nu, nv))
+        {
+          const float sgn = (x & 1u) ? -1.0f : 1.0f;
+          grad.dudx = (nu - tu) * sgn; grad.dvdx = (nv - tv) * sgn;
+        }
+        if(planeTexCoord(org, primaryDir(P, x, y ^ 1u), cornerPos[0], cornerPos[1], cornerPos[2], cornerU, cornerV, nu, nv))
+        {
+          const float sgn = (y & 1u) ? -1.0f : 1.0f;
+          grad.dudy = (nu - tu) * sgn; grad.dvdy = (nv - tv) * sgn;
+        }
       }
       const f3 viewDir = wPos - org;
       f3 N = normalize3(wNrm);  // frag_shader.frag:96-119
@@ -166,22 +213,22 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
         f3 T = normalize3(wTag), B = normalize3(wBin);
         T = normalize3(T - dot3(T, N) * N);
         B = normalize3(B - dot3(B, N) * N - dot3(B, T) * T);
-        const f4 tx = sampleTex(sc, mat.normalTexture, tu, tv, st);
+        const f4 tx = sampleTex(sc, mat.normalTexture, tu, tv, grad, st);
         f3 nrm = mk3(tx.x, tx.y, tx.z) * 2.0f - mk3(1.0f);
         nrm = normalize3(nrm);
         nrm = normalize3(T * nrm.x + B * nrm.y + N * nrm.z);
         N = nrm;
       }
-      const f3 baseColor = pbrGetBaseColor(sc, mat, tu, tv, st);
+      const f3 baseColor = pbrGetBaseColor(sc, mat, tu, tv, grad, st);
       float metalness, roughness;
-      pbrGetMetallicRoughness(sc, mat, tu, tv, metalness, roughness, st);
+      pbrGetMetallicRoughness(sc, mat, tu, tv, grad, metalness, roughness, st);
       const f3 albedo = (1.0f - metalness) * baseColor;
       const f3 V = normalize3(-viewDir);
       f3 color = mk3(0.0f);
       f3 emittance = mk3(mat.emissiveFactor[0], mat.emissiveFactor[1], mat.emissiveFactor[2]);
       if(mat.emissiveTexture > -1)
       {
-        const f4 tx = sampleTex(sc, mat.emissiveTexture, tu, tv, st);
+        const f4 tx = sampleTex(sc, mat.emissiveTexture, tu, tv, grad, st);
         emittance = emittance * mk3(tx.x, tx.y, tx.z);
       }
       const unsigned retap = (mat.pbrBaseColorTexture > -1 ? 1u : 0u) + (mat.metallicRoughnessTexture > -1 ? 1u : 0u);

@@ -98,8 +98,47 @@ VKRT_DEV f4 texBlend(const float* lut, const TexTap& tp, uint32_t p00, uint32_t 
   r.w = (t00.w * bx + t10.w * ax) * by + (t01.w * bx + t11.w * ax) * ay;
   return r;
 }
-// one texture by index through the descriptor table (G-buffer path; the path tracer's hit shader uses DevTexRef)
-VKRT_DEV f4 sampleTex(const DevScene& sc, int texIndex, float u, float v, ShadeStats& st)
+// one texture by index through the descriptor table at LOD 0 (G-buffer path; the path tracer's hit shader uses DevTexRef)
+VKRT_DEV f4 sampleTexLevel(const DevScene& sc, const DevTexture& tx, const uint32_t* levelOffsets, uint32_t level, float u, float v, const float* lut)
+{
+  const uint32_t ws = tx.width >> level, hs = tx.height >> level;
+  const uint32_t w = ws ? ws : 1u, h = hs ? hs : 1u;
+  TexTap tp;
+  texFootprint(level == 0u ? tx.offset : levelOffsets[level], w, h, (tx.srgb & 1u) != 0u, true, true, u, v, tp);
+  return texBlend(lut, tp, sc.texels[tp.i00], sc.texels[tp.i10], sc.texels[tp.i01], sc.texels[tp.i11]);
+}
+
+// log2 for the LOD computation, the same operation sequence on both sides (exponent from the bits, 2 atanh((m-1)/(m+1)) series
+// on m in (sqrt(1/2), sqrt(2)]): relative error < 1e-7, well inside what the Vulkan spec allows an implementation for lambda.
+VKRT_DEV float lodLog2(float x)
+{
+  const uint32_t b = (uint32_t)__float_as_int(x);
+  int e = (int)((b >> 23) & 255u) - 127;
+  float m = __int_as_float((int)((b & 0x007fffffu) | 0x3f800000u));
+  if(m > 1.41421356f)
+  {
+    m = m * 0.5f;
+    e += 1;
+  }
+  const float s = (m - 1.0f) / (m + 1.0f), s2 = s * s;
+  const float series = 1.0f + s2 * (0.333333333f + s2 * (0.2f + s2 * (0.142857143f + s2 * 0.111111111f)));
+  return (float)e + (2.0f * s * series) * 1.44269504f;
+}
+
+// Screen-space derivatives of the texture coordinates of one G-buffer pixel (what dFdx / dFdy of the interpolated
+// fragTexCoord give the fragment shader's implicit-LOD texture(), frag_shader.frag:96-125).
+struct TexGrad
+{
+  float dudx, dvdx, dudy, dvdy;
+  bool on;  // false: LOD 0 (VKRT_OPT_GBUFFER_MIPS = 0)
+};
+
+// texture() with implicit derivatives as the sampler of hello_vulkan.cpp:448-454 defines it: linear min / mag filter, linear
+// mip filter over the full chain, anisotropy up to 4.  Vulkan 1.3 spec chapter 16 "Image Operations": scale factors rho_x,
+// rho_y from the derivatives in texel units, eta = min(rho_max / rho_min, maxAniso), N = ceil(eta), lambda = log2(rho_max /
+// eta) clamped to the chain, N bilinear taps along the major axis at u(x - 1/2 + i / (N + 1)), each blended between the two
+// levels around lambda.
+VKRT_DEV f4 sampleTex(const DevScene& sc, int texIndex, float u, float v, const TexGrad& g, ShadeStats& st)
 {
   st.taps++;
   f4 r;
@@ -108,32 +147,75 @@ VKRT_DEV f4 sampleTex(const DevScene& sc, int texIndex, float u, float v, ShadeS
     r.x = r.y = r.z = r.w = 1.0f;
     return r;
   }
-  const DevTexture tx = sc.textures[texIndex];
-  TexTap tp;
-  texFootprint(tx.offset, tx.width, tx.height, tx.srgb != 0u, true, true, u, v, tp);
-  return texBlend(st.lut, tp, sc.texels[tp.i00], sc.texels[tp.i10], sc.texels[tp.i01], sc.texels[tp.i11]);
+  DevTexture tx = sc.textures[texIndex];
+  const uint32_t levels = tx.srgb >> 8;
+  if(!g.on || levels <= 1u)
+    return sampleTexLevel(sc, tx, nullptr, 0u, u, v, st.lut);
+  const uint32_t* levelOffsets = sc.texMips + (size_t)texIndex * VKRT_MAX_MIPS;
+  const float fw = (float)tx.width, fh = (float)tx.height;
+  const float mxu = g.dudx * fw, mxv = g.dvdx * fh, myu = g.dudy * fw, myv = g.dvdy * fh;
+  const float rx2 = mxu * mxu + mxv * mxv, ry2 = myu * myu + myv * myv;
+  const bool majorX = rx2 >= ry2;
+  const float rmax = sqrtf(majorX ? rx2 : ry2), rmin = sqrtf(majorX ? ry2 : rx2);
+  float eta = 1.0f;
+  if(rmin > 0.0f)
+    eta = glsl_min(rmax / rmin, 4.0f);
+  else if(rmax > 0.0f)
+    eta = 4.0f;
+  if(!(eta >= 1.0f))
+    eta = 1.0f;
+  const int N = (int)ceilf(eta);
+  const float scale = rmax / eta;
+  float lambda = 0.0f;
+  if(scale > 1.0f && scale < 3.0e38f)
+    lambda = lodLog2(scale);
+  else if(!(scale <= 1.0f))
+    lambda = (float)(levels - 1u);  // infinite or NaN footprint: the smallest level
+  lambda = glsl_clamp(lambda, 0.0f, (float)(levels - 1u));
+  const float fl = floorf(lambda), delta = lambda - fl;
+  const uint32_t hi = (uint32_t)fl, lo = hi + 1u < levels ? hi + 1u : levels - 1u;
+  const float du = majorX ? g.dudx : g.dudy, dv = majorX ? g.dvdx : g.dvdy;
+  r.x = r.y = r.z = r.w = 0.0f;
+  for(int i = 1; i <= N; i++)
+  {
+    const float o = (float)i / (float)(N + 1) - 0.5f;
+    float tu = u + o * du, tv = v + o * dv;
+    if(!(fabsf(tu) < 1.0e9f) || !(fabsf(tv) < 1.0e9f))
+    {
+      tu = u;
+      tv = v;
+    }
+    const f4 a = sampleTexLevel(sc, tx, levelOffsets, hi, tu, tv, st.lut), b = sampleTexLevel(sc, tx, levelOffsets, lo, tu, tv, st.lut);
+    r.x = r.x + (a.x * (1.0f - delta) + b.x * delta);
+    r.y = r.y + (a.y * (1.0f - delta) + b.y * delta);
+    r.z = r.z + (a.z * (1.0f - delta) + b.z * delta);
+    r.w = r.w + (a.w * (1.0f - delta) + b.w * delta);
+  }
+  const float inv = 1.0f / (float)N;
+  r.x = r.x * inv; r.y = r.y * inv; r.z = r.z * inv; r.w = r.w * inv;
+  return r;
 }
 
 // gltf.glsl:26-32
-VKRT_DEV f3 pbrGetBaseColor(const DevScene& sc, const GltfPBRMaterial& mat, float tu, float tv, ShadeStats& st)
+VKRT_DEV f3 pbrGetBaseColor(const DevScene& sc, const GltfPBRMaterial& mat, float tu, float tv, const TexGrad& g, ShadeStats& st)
 {
   f3 color = mk3(mat.pbrBaseColorFactor[0], mat.pbrBaseColorFactor[1], mat.pbrBaseColorFactor[2]);
   if(mat.pbrBaseColorTexture > -1)
   {
-    const f4 t = sampleTex(sc, mat.pbrBaseColorTexture, tu, tv, st);
+    const f4 t = sampleTex(sc, mat.pbrBaseColorTexture, tu, tv, g, st);
     color = color * mk3(t.x, t.y, t.z);
   }
   return color;
 }
 // gltf.glsl:34-45
-VKRT_DEV void pbrGetMetallicRoughness(const DevScene& sc, const GltfPBRMaterial& mat, float tu, float tv, float& metallic,
-                                      float& roughness, ShadeStats& st)
+VKRT_DEV void pbrGetMetallicRoughness(const DevScene& sc, const GltfPBRMaterial& mat, float tu, float tv, const TexGrad& g,
+                                      float& metallic, float& roughness, ShadeStats& st)
 {
   metallic = mat.metallicFactor;
   roughness = mat.roughnessFactor;
   if(mat.metallicRoughnessTexture > -1)
   {
-    const f4 t = sampleTex(sc, mat.metallicRoughnessTexture, tu, tv, st);
+    const f4 t = sampleTex(sc, mat.metallicRoughnessTexture, tu, tv, g, st);
     roughness *= t.y;
     metallic *= t.z;
   }

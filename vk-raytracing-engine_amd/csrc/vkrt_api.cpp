@@ -81,7 +81,7 @@ struct vkrt_scene
   WfTiming wfTiming{};
   bool wfTimed = false;
   // execution options (include/vkrt.h vkrt_option); index = option id
-  int opt[9] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT};
+  int opt[10] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1};
   bool wavefront = true;  // execution mode the acceleration structure was built for (opt[VKRT_OPT_MODE] at vkrt_accel_build)
 };
 
@@ -147,6 +147,36 @@ int validate(const vkrt_scene_desc* d)
   return VKRT_OK;
 }
 
+// Mip chain of one RGBA8 image as nvvk::cmdGenerateMipmaps builds it (hello_vulkan.cpp:496): level L is blitted from level
+// L - 1 with VK_FILTER_LINEAR to max(1, size / 2).  vkCmdBlitImage semantics: destination texel centre x + 0.5 maps to the
+// unnormalised source coordinate (x + 0.5) * srcSize / dstSize, filtered bilinearly around it with clamp-to-edge; an sRGB
+// image is filtered in linear space and re-encoded.  Even sizes reduce to the 2x2 box average.
+float srgbEncode(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
+void downsampleLevel(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, bool srgb, const float* lut512)
+{
+  for(uint32_t y = 0; y < dh; y++)
+    for(uint32_t x = 0; x < dw; x++)
+    {
+      const float fu = ((float)x + 0.5f) * ((float)sw / (float)dw) - 0.5f, fv = ((float)y + 0.5f) * ((float)sh / (float)dh) - 0.5f;
+      const float flx = floorf(fu), fly = floorf(fv), ax = fu - flx, ay = fv - fly;
+      auto cl = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+      const int x0 = cl((int)flx, (int)sw), x1 = cl((int)flx + 1, (int)sw), y0 = cl((int)fly, (int)sh), y1 = cl((int)fly + 1, (int)sh);
+      const uint32_t p[4] = {src[(size_t)y0 * sw + x0], src[(size_t)y0 * sw + x1], src[(size_t)y1 * sw + x0], src[(size_t)y1 * sw + x1]};
+      uint32_t out = 0;
+      for(int c = 0; c < 4; c++)
+      {
+        const uint32_t base = (srgb && c < 3) ? 0u : 256u;
+        const float t00 = lut512[base + ((p[0] >> (8 * c)) & 255u)], t10 = lut512[base + ((p[1] >> (8 * c)) & 255u)];
+        const float t01 = lut512[base + ((p[2] >> (8 * c)) & 255u)], t11 = lut512[base + ((p[3] >> (8 * c)) & 255u)];
+        float v = (t00 * (1.0f - ax) + t10 * ax) * (1.0f - ay) + (t01 * (1.0f - ax) + t11 * ax) * ay;
+        if(srgb && c < 3) v = srgbEncode(v);
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        out |= (uint32_t)(v * 255.0f + 0.5f) << (8 * c);
+      }
+      dst[(size_t)y * dw + x] = out;
+    }
+}
+
 // execution mode: wavefront pipeline (default) or the single persistent megakernel
 bool useWavefront(const vkrt_scene* s) { return s->opt[VKRT_OPT_MODE] == 1; }
 
@@ -161,6 +191,7 @@ int clampOption(int option, int v)
     case VKRT_OPT_TRI_THRESHOLD: return std::max(0, std::min(65, v));
     case VKRT_OPT_WF_SHARE_PERIOD: return std::max(0, std::min(255, v));
     case VKRT_OPT_WF_SHARE_FLAGS: return v & 1;
+    case VKRT_OPT_GBUFFER_MIPS: return v ? 1 : 0;
   }
   return v;
 }
@@ -173,7 +204,8 @@ void optionsFromEnvironment(vkrt_scene* s)
   if((e = getenv("VKRT_BVH")) && !strcmp(e, "bvh2")) s->opt[VKRT_OPT_BVH_LAYOUT] = 0;
   const struct { const char* name; int option; } ints[] = {{"VKRT_WF_SUBFRAMES", VKRT_OPT_WF_SUBFRAMES}, {"VKRT_WF_TRAV_BLOCK", VKRT_OPT_WF_TRAV_BLOCK},
                                                           {"VKRT_WF_SHARE", VKRT_OPT_WF_SHARE}, {"VKRT_TRI_THRESHOLD", VKRT_OPT_TRI_THRESHOLD},
-                                                          {"VKRT_WF_SHARE_PERIOD", VKRT_OPT_WF_SHARE_PERIOD}, {"VKRT_WF_SHARE_FLAGS", VKRT_OPT_WF_SHARE_FLAGS}};
+                                                          {"VKRT_WF_SHARE_PERIOD", VKRT_OPT_WF_SHARE_PERIOD}, {"VKRT_WF_SHARE_FLAGS", VKRT_OPT_WF_SHARE_FLAGS},
+                                                          {"VKRT_GBUFFER_MIPS", VKRT_OPT_GBUFFER_MIPS}};
   for(const auto& k : ints)
     if((e = getenv(k.name)))
       s->opt[k.option] = clampOption(k.option, atoi(e));
@@ -302,19 +334,6 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   }
   if((rc = upload(s, inst.data(), inst.size(), &D.instances)) != VKRT_OK) return bail(rc);
   // textures: RGBA8 pool + table + sRGB decode table
-  std::vector<DevTexture> table(d->texture_count);
-  std::vector<uint32_t> pool;
-  for(uint32_t t = 0; t < d->texture_count; t++)
-  {
-    const vkrt_texture& tx = d->textures[t];
-    table[t] = DevTexture{(uint32_t)pool.size(), tx.width, tx.height, tx.is_srgb ? 1u : 0u};
-    const size_t n = (size_t)tx.width * tx.height;
-    const size_t at = pool.size();
-    pool.resize(at + n);
-    memcpy(&pool[at], tx.rgba8, n * 4);
-  }
-  if(pool.empty())
-    pool.push_back(0xffffffffu);  // shading always issues its texel loads (to texel 0 when a material has no texture)
   float lut[512];
   for(int i = 0; i < 256; i++)
   {
@@ -322,6 +341,33 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
     lut[i] = (c <= 0.04045f) ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f);
     lut[256 + i] = c;
   }
+  std::vector<DevTexture> table(d->texture_count);
+  std::vector<uint32_t> mipTable((size_t)d->texture_count * VKRT_MAX_MIPS, 0u);
+  std::vector<uint32_t> pool;
+  for(uint32_t t = 0; t < d->texture_count; t++)
+  {
+    const vkrt_texture& tx = d->textures[t];
+    const size_t n = (size_t)tx.width * tx.height;
+    size_t at = pool.size();
+    pool.resize(at + n);
+    memcpy(&pool[at], tx.rgba8, n * 4);
+    // the mip chain behind level 0 (sampled by the hybrid G-buffer's implicit-LOD texture(); the path tracer reads level 0)
+    uint32_t levels = 1, w = tx.width, h = tx.height;
+    mipTable[(size_t)t * VKRT_MAX_MIPS] = (uint32_t)at;
+    while((w > 1 || h > 1) && levels < VKRT_MAX_MIPS)
+    {
+      const uint32_t dw = std::max(1u, w / 2), dh = std::max(1u, h / 2);
+      const size_t to = pool.size();
+      pool.resize(to + (size_t)dw * dh);
+      downsampleLevel(&pool[at], w, h, &pool[to], dw, dh, tx.is_srgb != 0, lut);
+      mipTable[(size_t)t * VKRT_MAX_MIPS + levels] = (uint32_t)to;
+      at = to; w = dw; h = dh;
+      levels++;
+    }
+    table[t] = DevTexture{mipTable[(size_t)t * VKRT_MAX_MIPS], tx.width, tx.height, (tx.is_srgb ? 1u : 0u) | (levels << 8)};
+  }
+  if(pool.empty())
+    pool.push_back(0xffffffffu);  // shading always issues its texel loads (to texel 0 when a material has no texture)
   // materials, with the descriptors of their textures folded in (DevMaterial)
   std::vector<DevMaterial> mats(d->material_count);
   for(uint32_t i = 0; i < d->material_count; i++)
@@ -338,12 +384,13 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
         const DevTexture& t = table[(size_t)idx[k]];
         if(t.width == 0u || t.height == 0u || t.width > 65535u || t.height > 65535u)
           return bail(fail(VKRT_ERR_UNSUPPORTED, "texture %d is %ux%u (supported: 1..65535 per side)", idx[k], t.width, t.height));
-        r = DevTexRef{t.offset, t.width | (t.height << 16), 1u | (t.srgb ? 2u : 0u), 0u};
+        r = DevTexRef{t.offset, t.width | (t.height << 16), 1u | ((t.srgb & 1u) ? 2u : 0u), 0u};
       }
     }
   }
   if((rc = upload(s, mats.data(), mats.size(), &D.materials)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, table.data(), table.size(), &D.textures)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, mipTable.data(), mipTable.size(), &D.texMips)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, pool.data(), pool.size(), &D.texels)) != VKRT_OK) return bail(rc);
   const float* lutDev = nullptr;
   if((rc = upload(s, lut, 512, &lutDev)) != VKRT_OK) return bail(rc);
@@ -357,6 +404,7 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   D.shareMinIdle = 0;
   D.sharePeriodMask = 0;
   D.shareFlags = 0;
+  D.gbufferMips = 1;
 
   void* p = nullptr;
   if(hipMalloc(&p, 64) != hipSuccess) return bail(fail(VKRT_ERR_OUT_OF_MEMORY, "hipMalloc(work counter)"));
@@ -401,7 +449,7 @@ int vkrt_scene_set_option(vkrt_scene* s, int option, int value)
 {
   if(!s)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "scene is NULL");
-  if(option < VKRT_OPT_MODE || option > VKRT_OPT_WF_SHARE_FLAGS)
+  if(option < VKRT_OPT_MODE || option > VKRT_OPT_GBUFFER_MIPS)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
   if(clampOption(option, value) != value)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "option %d: value %d out of range", option, value);
@@ -413,7 +461,7 @@ int vkrt_scene_get_option(const vkrt_scene* s, int option, int* value)
 {
   if(!s || !value)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
-  if(option < VKRT_OPT_MODE || option > VKRT_OPT_WF_SHARE_FLAGS)
+  if(option < VKRT_OPT_MODE || option > VKRT_OPT_GBUFFER_MIPS)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
   *value = s->opt[option];
   return VKRT_OK;
@@ -855,6 +903,7 @@ int gbufferImpl(vkrt_scene* s, const float clearColor[4], int lightsCount, const
     return rc;
   if(P.localRows == 0)
     return VKRT_OK;
+  P.sc.gbufferMips = (uint32_t)s->opt[VKRT_OPT_GBUFFER_MIPS];
   NrdPlanes np{};
   if(nrd)
   {
