@@ -83,10 +83,10 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--triangles", type=int, default=262144)
     ap.add_argument("--scene-seed", type=int, default=1)
-    ap.add_argument("--build", choices=["sah", "lbvh"], default="sah")
+    ap.add_argument("--build", choices=["sah", "lbvh", "ploc"], default="ploc")
     ap.add_argument("--no-textures", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-builder", action="store_true", help="skip the short run with the builder that was not selected")
+    ap.add_argument("--no-other-builder", action="store_true", help="skip the short runs with the builders that were not selected")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--weak", action="store_true", help="N > 1: N x 1080p pixels instead of one fixed 3840x2160 frame")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo for rehearsals")
@@ -140,9 +140,9 @@ def main():
     # ---- scene upload + acceleration structure (timed apart from the trace) ----------------------------------
     r = Renderer(flat, device=local_rank, build=None)
     builds = {}
-    other = "lbvh" if args.build == "sah" else "sah"
+    others = [k for k in ("lbvh", "ploc", "sah") if k != args.build]
     torch.cuda.synchronize(dev)
-    for kind in ([other] if (rank == 0 and world == 1 and not args.no_other_builder) else []) + [args.build]:
+    for kind in (others if (rank == 0 and world == 1 and not args.no_other_builder) else []) + [args.build]:
         t0 = time.perf_counter()
         r.build(kind)
         torch.cuda.synchronize(dev)
@@ -306,13 +306,14 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "k_pathtrace", "kernel_ms": float(np.mean(frame_ms)), "algorithmic_bytes_per_launch": own}
 
-        # ---- the builder that was not selected: a short run beside the headline ---------------------------------------
+        # ---- the builders that were not selected: a short run each beside the headline ---------------------------------
         if world == 1 and not args.no_other_builder:
-            r.build(other)
-            for f in range(1):
-                step(f)
-            dt, _, c2 = timed_frames(1, 2)
-            builds[other]["Mrays_s"] = (c2["rays_closest"] + c2["rays_shadow"]) / dt / 1e6
+            for other in others:
+                r.build(other)
+                for f in range(1):
+                    step(f)
+                dt, _, c2 = timed_frames(1, 2)
+                builds[other]["Mrays_s"] = (c2["rays_closest"] + c2["rays_shadow"]) / dt / 1e6
             builds[args.build]["Mrays_s"] = mrays
             r.build(args.build)
 

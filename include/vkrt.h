@@ -109,9 +109,11 @@ typedef struct vkrt_scene_desc {
 /* Acceleration-structure build selection (replaces
  * VK_BUILD_ACCELERATION_STRUCTURE_PREFER_FAST_TRACE_BIT_KHR, hello_vulkan.cpp:1010,1046). */
 enum vkrt_build_flags {
-  VKRT_BUILD_LBVH_GPU = 0x1,  /* Morton-code LBVH built by HIP kernels on the device  */
-  VKRT_BUILD_SAH_HOST = 0x2,  /* binned-SAH BVH built by the C++ host, then uploaded  */
-  VKRT_BUILD_DEFAULT  = 0x2
+  VKRT_BUILD_LBVH_GPU = 0x1,  /* Morton-code radix tree built by HIP kernels on the device (fastest build)  */
+  VKRT_BUILD_SAH_HOST = 0x2,  /* binned-SAH BVH built by the C++ host, then uploaded (best tree, ~15x the build time)  */
+  VKRT_BUILD_PLOC_GPU = 0x4,  /* device build for trace speed: locally-ordered clustering over the Morton order (ploc.hip), upper
+                                 levels re-built with a full-sweep SAH over the clustered subtrees (lbvh.hip)  */
+  VKRT_BUILD_DEFAULT  = 0x4   /* the reference builds on the device with PREFER_FAST_TRACE: so does the default  */
 };
 
 /* Image-space sharding (replaces the single vkCmdTraceRaysKHR(W,H,1) grid,

@@ -23,7 +23,7 @@ def mismatch_fraction(a, b):
 def renderers(cornell_flat):
     from vkrt_amd.renderer import Renderer
 
-    rs = {k: Renderer(cornell_flat, device=0, build=k) for k in ("sah", "lbvh")}
+    rs = {k: Renderer(cornell_flat, device=0, build=k) for k in ("sah", "lbvh", "ploc")}
     yield rs
     for r in rs.values():
         r.close()
@@ -70,7 +70,7 @@ def _ray_set(n, seed):
     return o, d.astype(np.float32)
 
 
-@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+@pytest.mark.parametrize("kind", ["sah", "lbvh", "ploc"])
 def test_closest_hit_rays_match_oracle(renderers, cornell_oracle, kind):
     o, d = _ray_set(40000, 11)
     t0, u0, v0, g0, _ = cornell_oracle.trace_rays(o, d)
@@ -82,7 +82,7 @@ def test_closest_hit_rays_match_oracle(renderers, cornell_oracle, kind):
         assert np.array_equal(a[hit].view(np.uint32), b[hit].view(np.uint32))
 
 
-@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+@pytest.mark.parametrize("kind", ["sah", "lbvh", "ploc"])
 def test_any_hit_rays_match_oracle(renderers, cornell_oracle, kind):
     o, d = _ray_set(40000, 12)
     _, _, _, g0, _ = cornell_oracle.trace_rays(o, d, tmin=0.001, tmax=3.0, any_hit=True)
@@ -91,7 +91,7 @@ def test_any_hit_rays_match_oracle(renderers, cornell_oracle, kind):
     assert 0.05 < (g0 >= 0).mean() < 0.95
 
 
-@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+@pytest.mark.parametrize("kind", ["sah", "lbvh", "ploc"])
 def test_config1_cornell_256_bit_identical(renderers, cornell_oracle, cornell_flat, kind):
     """BASELINE config 1: cornell 256x256, 1 spp, depth 1, frame 0, seed 0."""
     from vkrt_amd.flat_scene import make_push_constants
@@ -251,7 +251,7 @@ def atrium_small():
     return flat, info, atrium.DEFAULT_CAMERA
 
 
-@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+@pytest.mark.parametrize("kind", ["sah", "lbvh", "ploc"])
 def test_atrium_small_textured_full_image(atrium_small, kind):
     import oracle_py
     from vkrt_amd.flat_scene import make_push_constants
@@ -412,7 +412,7 @@ def _coincident_layers_scene(layers=5, n=12):
     return FlatScene(pos, nrm, tan, uv, idx, pm, mats, lights, nodes, [])
 
 
-@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+@pytest.mark.parametrize("kind", ["sah", "lbvh", "ploc"])
 def test_coincident_geometry_tie_rule(kind):
     """Equal-t hits: oracle and GPU must pick the same triangle everywhere (ray queries and the full pipeline, with the
     wave-level work sharing active, where several lanes publish candidates for one ray)."""
@@ -528,7 +528,7 @@ def _triangle_soup(n=6000, seed=21):
     return FlatScene(pos, nrm, tan, uv, idx, pm, mats, lights, nodes, [])
 
 
-@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+@pytest.mark.parametrize("kind", ["sah", "lbvh", "ploc"])
 def test_triangle_soup_ray_queries_equal_brute_force(kind):
     """Closest-hit and any-hit queries on a hostile triangle set: the GPU tree walk and the oracle's tree walk must return
     exactly what the oracle's brute-force loop over all triangles returns (rays from everywhere, including axis-parallel ones
@@ -611,7 +611,7 @@ def test_non_power_of_two_and_degenerate_textures(atrium_small):
     r.close()
 
 
-@pytest.mark.parametrize("kind", ["sah", "lbvh"])
+@pytest.mark.parametrize("kind", ["sah", "lbvh", "ploc"])
 def test_empty_single_triangle_and_ragged_index_scenes(kind):
     """Edge inputs of the scene contract: no instances at all (every ray misses), one triangle (a leaf root), and a primMesh
     whose indexCount is not a multiple of three (the trailing indices are ignored, primitiveCount = indexCount / 3,
@@ -707,3 +707,47 @@ def test_scene_options_are_per_handle_and_do_not_change_pixels(atrium_small):
         r.close()
     assert modes[0] == "wavefront" and modes[-1] == "megakernel"
     assert len(set(hashes)) == 1, dict(zip(map(str, variants), hashes))
+
+
+@pytest.mark.gpu
+def test_device_builders_tree_quality_and_degenerate_input(atrium_small):
+    """The three builders on one scene: the clustered device tree (ploc.hip) must beat the Morton radix tree's SAH cost and come
+    close to the host's binned-SAH tree; every tree holds every triangle exactly once.  A pile of identical triangles
+    (all distances tie) must still build in a few passes and trace like the oracle."""
+    import oracle_py
+    from vkrt_amd.flat_scene import LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, FlatScene
+    from vkrt_amd.renderer import Renderer
+
+    flat, info, _ = atrium_small
+    cost = {}
+    for kind in ("sah", "lbvh", "ploc"):
+        r = Renderer(flat, device=0, build=kind)
+        a = r.accel_info()
+        cost[kind] = a["sah_cost"]
+        assert a["triangle_count"] == flat.instanced_triangle_count and a["triangle_bytes"] == 48 * a["triangle_count"]
+        r.close()
+    assert cost["ploc"] < 0.97 * cost["lbvh"], cost
+    assert cost["ploc"] < 1.10 * cost["sah"], cost
+
+    n = 3000  # identical triangles: every union has the same area
+    pos = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (n, 1))
+    idx = np.arange(3 * n, dtype=np.uint32)
+    pm = np.zeros(1, PRIM_DTYPE); pm[0] = (0, 3 * n, 0, 3 * n, 0)
+    mats = np.zeros(1, MAT_DTYPE)
+    mats[0]["pbrBaseColorFactor"] = [0.8, 0.8, 0.8, 1.0]
+    mats[0]["pbrBaseColorTexture"] = mats[0]["metallicRoughnessTexture"] = mats[0]["normalTexture"] = mats[0]["emissiveTexture"] = -1
+    mats[0]["roughnessFactor"] = 1.0
+    nodes = np.zeros(1, NODE_DTYPE); nodes[0]["worldMatrix"] = np.eye(4, dtype=np.float32).ravel()
+    lights = np.zeros(1, LIGHT_DTYPE); lights[0] = ((0.3, 0.3, 2.0), (1, 1, 1), 10.0, 0)
+    pile = FlatScene(pos, np.tile(np.array([0, 0, 1], np.float32), (3 * n, 1)), np.tile(np.array([1, 0, 0, 1], np.float32), (3 * n, 1)),
+                     np.zeros((3 * n, 2), np.float32), idx, pm, mats, lights, nodes, [])
+    orc = oracle_py.OracleScene(pile)
+    rng = np.random.default_rng(5)
+    o = np.concatenate([rng.uniform(-0.5, 1.5, (4000, 2)), np.full((4000, 1), 3.0)], 1).astype(np.float32)
+    d = np.tile(np.array([[0, 0, -1]], np.float32), (4000, 1)) + rng.normal(0, 0.05, (4000, 3)).astype(np.float32)
+    t0, u0, v0, g0, _ = orc.trace_rays(o, d)
+    r = Renderer(pile, device=0, build="ploc")
+    t1, u1, v1, g1 = r.trace_rays(o, d)
+    r.close()
+    assert np.array_equal(g0, g1) and 0.1 < (g0 >= 0).mean() < 0.9
+    assert np.array_equal(t0[g0 >= 0].view(np.uint32), t1[g0 >= 0].view(np.uint32))

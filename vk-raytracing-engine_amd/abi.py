@@ -169,6 +169,7 @@ assert C.sizeof(Node) == 68
 
 VKRT_BUILD_LBVH_GPU = 0x1
 VKRT_BUILD_SAH_HOST = 0x2
+VKRT_BUILD_PLOC_GPU = 0x4
 VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1
 VKRT_TRACE_COUNT_TRAVERSAL = 0x2
 VKRT_TRACE_TIME_KERNELS = 0x4

@@ -44,8 +44,14 @@ struct LbvhResult
   bool hasWide = false;
 };
 
-// sc must already hold the uploaded positions / indices / instances.
+// Binary hierarchy over the Morton-sorted triangles by parallel locally-ordered clustering (ploc.hip): fills the same arrays as
+// k_hierarchy + k_fit of lbvh.hip (children, parents, boxes; range[i] = (0, triangles below i - 1)); node 0 is the root.
+int ploc_cluster_device(uint32_t T, const unsigned* order, const float* triBox, hipStream_t stream, int2* children, int2* range, int* parentInternal,
+                        int* parentLeaf, float* nodeBox, unsigned* passes, std::string& err);
+
+// sc must already hold the uploaded positions / indices / instances.  ploc: cluster (ploc.hip, one triangle per leaf) instead of
+// the Morton radix tree.
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4, bool wantWide = false);
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4, bool wantWide = false, bool ploc = false);
 
 }  // namespace vkrt

@@ -12,9 +12,12 @@
 //   k_pack      48-byte triangle records in sorted (leaf) order
 // Triangle arithmetic is the same sequence as the host flatten (bvh_host.cpp) so both builders
 // hand bit-identical triangles to the traversal kernel.
+// VKRT_BUILD_PLOC_GPU swaps k_hierarchy + k_fit for the clustering of ploc.hip (better trees, a few more passes).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string>
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -330,6 +333,160 @@ __global__ void k_depth(unsigned kLeaf, int n, const int2* range, const int* par
   atomicMax(maxDepth, d);
 }
 
+// ---- SAH top of the tree ------------------------------------------------------------------------------------------------
+// The upper levels of a tree carry most of its SAH cost, and that is where a Morton split or a window-limited clustering is
+// furthest from what the surface-area heuristic would choose.  After the binary hierarchy stands, the nodes with more than K
+// triangles below them are re-built: the subtrees hanging under them (<= K triangles each, "frontier") become the primitives
+// of a full-sweep SAH build (a few thousand boxes; on the host: microseconds per split, no device round trips per level), whose
+// internal nodes take over the ids of the nodes they replace (a binary tree over F frontier entries has F - 1 internal nodes,
+// exactly the nodes above the frontier; the root keeps id 0).  HLBVH's recipe (Garanzha, Pantaleoni, McAllister 2011,
+// "Simpler and Faster HLBVH with Work Queues", section 4) applied to whatever built the bottom.
+struct TopEntry  // 32 B
+{
+  int ref;  // >= 0 internal node, < 0 ~(leaf position)
+  int count;
+  float box[6];
+};
+struct TopNode  // 40 B
+{
+  int id, left, right, count;
+  float box[6];
+};
+
+__global__ void k_top_select(int n, unsigned K, unsigned cap, const unsigned* __restrict__ order, const float* __restrict__ triBox,
+                             const int2* __restrict__ range, const int* __restrict__ parentInternal, const int* __restrict__ parentLeaf,
+                             const float* __restrict__ nodeBox, TopEntry* frontier, int* topIds, unsigned* counters)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= 2 * n - 1)
+    return;
+  const bool leaf = k >= n - 1;
+  const int pos = k - (n - 1);
+  const unsigned cnt = leaf ? 1u : (unsigned)(range[k].y - range[k].x + 1);
+  if(cnt > K)
+  {
+    const unsigned at = atomicAdd(&counters[1], 1u);
+    if(at < cap)
+      topIds[at] = k;
+    return;
+  }
+  const int parent = leaf ? parentLeaf[pos] : parentInternal[k];
+  if(parent < 0 || (unsigned)(range[parent].y - range[parent].x + 1) <= K)
+    return;  // inside a frontier subtree
+  const unsigned at = atomicAdd(&counters[0], 1u);
+  if(at >= cap)
+    return;
+  TopEntry e;
+  e.ref = leaf ? ~pos : k;
+  e.count = (int)cnt;
+  const float* b = leaf ? &triBox[6 * (size_t)order[pos]] : &nodeBox[6 * (size_t)k];
+#pragma unroll
+  for(int q = 0; q < 6; q++) e.box[q] = b[q];
+  frontier[at] = e;
+}
+
+__global__ void k_top_apply(unsigned m, const TopNode* __restrict__ top, int2* children, int2* range, int* parentInternal, int* parentLeaf, float* nodeBox)
+{
+  const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= m)
+    return;
+  const TopNode t = top[k];
+  children[t.id] = make_int2(t.left, t.right);
+  range[t.id] = make_int2(0, t.count - 1);  // (only the triangle count of a node is used from here on)
+#pragma unroll
+  for(int q = 0; q < 6; q++) nodeBox[6 * (size_t)t.id + q] = t.box[q];
+  if(t.left >= 0) parentInternal[t.left] = t.id; else parentLeaf[~t.left] = t.id;
+  if(t.right >= 0) parentInternal[t.right] = t.id; else parentLeaf[~t.right] = t.id;
+  if(t.id == 0)
+    parentInternal[0] = -1;
+}
+
+// full-sweep SAH over the frontier entries [a, b) of `e` (reordered in place); returns the reference of the subtree's root
+struct TopBuilder
+{
+  std::vector<TopEntry>& e;
+  const std::vector<int>& ids;  // ids for the new internal nodes; ids[0] = 0 goes to the root
+  std::vector<TopNode>& out;
+  size_t nextId = 0;
+  std::vector<float> rightArea;
+  std::vector<int> rightCount;
+
+  static float area(const float* b)
+  {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+  static void grow(float* b, const float* o)
+  {
+    for(int q = 0; q < 3; q++)
+    {
+      b[q] = std::min(b[q], o[q]);
+      b[3 + q] = std::max(b[3 + q], o[3 + q]);
+    }
+  }
+  int build(size_t a, size_t b)
+  {
+    if(b - a == 1)
+      return e[a].ref;
+    const size_t n = b - a;
+    TopNode node;
+    node.id = ids[nextId++];
+    float best = INFINITY;
+    int bestAxis = 0;
+    size_t bestSplit = 1;
+    rightArea.resize(std::max(rightArea.size(), n + 1));
+    rightCount.resize(std::max(rightCount.size(), n + 1));
+    for(int axis = 0; axis < 3; axis++)
+    {
+      std::sort(e.begin() + a, e.begin() + b, [axis](const TopEntry& x, const TopEntry& y) {
+        const float cx = x.box[axis] + x.box[3 + axis], cy = y.box[axis] + y.box[3 + axis];
+        return cx < cy || (cx == cy && x.ref < y.ref);
+      });
+      float acc[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int cnt = 0;
+      for(size_t k = n; k-- > 1;)  // right parts [k, n)
+      {
+        grow(acc, e[a + k].box);
+        cnt += e[a + k].count;
+        rightArea[k] = area(acc);
+        rightCount[k] = cnt;
+      }
+      float left[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int lc = 0;
+      for(size_t k = 1; k < n; k++)  // left part [0, k)
+      {
+        grow(left, e[a + k - 1].box);
+        lc += e[a + k - 1].count;
+        const float c = area(left) * (float)lc + rightArea[k] * (float)rightCount[k];
+        if(c < best)
+        {
+          best = c; bestAxis = axis; bestSplit = k;
+        }
+      }
+    }
+    if(bestAxis != 2)
+      std::sort(e.begin() + a, e.begin() + b, [bestAxis](const TopEntry& x, const TopEntry& y) {
+        const float cx = x.box[bestAxis] + x.box[3 + bestAxis], cy = y.box[bestAxis] + y.box[3 + bestAxis];
+        return cx < cy || (cx == cy && x.ref < y.ref);
+      });
+    float bx[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for(size_t k = a; k < b; k++)
+    {
+      grow(bx, e[k].box);
+      cnt += e[k].count;
+    }
+    for(int q = 0; q < 6; q++) node.box[q] = bx[q];
+    node.count = cnt;
+    const size_t slot = out.size();
+    out.push_back(node);
+    const int l = build(a, a + bestSplit), r = build(a + bestSplit, b);
+    out[slot].left = l;
+    out[slot].right = r;
+    return node.id;
+  }
+};
+
 struct Temp
 {
   std::vector<void*> ptrs;
@@ -366,9 +523,13 @@ struct Temp
   } while(0)
 
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide)
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide, bool ploc)
 {
-  const unsigned kLeaf = leafSize < 1u ? 1u : (leafSize > 8u ? 8u : leafSize);
+  bool topSah = ploc;  // the FAST_TRACE device build re-builds its upper levels with SAH; the radix tree stays the pure fast build
+  if(const char* e = getenv("VKRT_TOP_SAH"))  // test hook: force on / off for either builder
+    topSah = atoi(e) != 0;
+  // (clustered subtrees are not runs of the Morton order, so the PLOC tree keeps one triangle per leaf)
+  const unsigned kLeaf = ploc ? 1u : (leafSize < 1u ? 1u : (leafSize > 8u ? 8u : leafSize));
   out = LbvhResult{};
   std::vector<uint32_t> firstGid(instCount + 1, 0), firstIndex(instCount, 0), vertexOffset(instCount, 0);
   std::vector<int32_t> material(instCount, 0);
@@ -453,13 +614,66 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
   LB_TRY(tmp.alloc(&parentLeaf, T));
   LB_TRY(tmp.alloc(&nodeBox, (size_t)(T - 1) * 6));
   LB_TRY(tmp.alloc(&arrive, T - 1));
-  LB_TRY(tmp.alloc(&scalars, 4));
+  LB_TRY(tmp.alloc(&scalars, 4));  // [0] maxDepth, [1] sah accum, [2] frontier entries, [3] nodes above the frontier
   LB_TRY(hipMemsetAsync(arrive, 0, (size_t)(T - 1) * 4, stream));
   LB_TRY(hipMemsetAsync(scalars, 0, 16, stream));
-  hipLaunchKernelGGL(k_hierarchy, dim3(G), dim3(B), 0, stream, (int)T, (const unsigned long long*)keysB, children, range, parentInternal,
-                     parentLeaf);
-  hipLaunchKernelGGL(k_fit, dim3(G), dim3(B), 0, stream, (int)T, order, (const float*)triBox, (const int2*)children,
-                     (const int*)parentInternal, (const int*)parentLeaf, nodeBox, arrive);
+  if(ploc)
+  {
+    const int rcp = ploc_cluster_device(T, order, (const float*)triBox, stream, children, range, parentInternal, parentLeaf, nodeBox, nullptr, out.error);
+    if(rcp != VKRT_OK)
+    {
+      (void)hipFree(out.nodes); (void)hipFree(out.tris); (void)hipFree(out.triShade);
+      out.nodes = out.tris = out.triShade = nullptr;
+      return rcp;
+    }
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_hierarchy, dim3(G), dim3(B), 0, stream, (int)T, (const unsigned long long*)keysB, children, range, parentInternal,
+                       parentLeaf);
+    hipLaunchKernelGGL(k_fit, dim3(G), dim3(B), 0, stream, (int)T, order, (const float*)triBox, (const int2*)children,
+                       (const int*)parentInternal, (const int*)parentLeaf, nodeBox, arrive);
+  }
+  if(topSah && T > 4096u)
+  {
+    // re-build the levels above subtrees of <= K triangles with a full-sweep SAH over those subtrees (see k_top_select)
+    unsigned K = std::max(16u, T / 2048u);
+    if(const char* e = getenv("VKRT_TOP_SAH_LEAF"))  // test hook: triangles per frontier subtree
+      K = (unsigned)std::max(8, atoi(e));
+    const unsigned cap = 32768u;
+    TopEntry* dFrontier;
+    int* dTopIds;
+    TopNode* dTop;
+    LB_TRY(tmp.alloc(&dFrontier, cap));
+    LB_TRY(tmp.alloc(&dTopIds, cap));
+    LB_TRY(tmp.alloc(&dTop, cap));
+    LB_TRY(hipMemsetAsync(&scalars[2], 0, 8, stream));
+    hipLaunchKernelGGL(k_top_select, dim3((2 * T - 1 + B - 1) / B), dim3(B), 0, stream, (int)T, K, cap, order, (const float*)triBox, (const int2*)range,
+                       (const int*)parentInternal, (const int*)parentLeaf, (const float*)nodeBox, dFrontier, dTopIds, &scalars[2]);
+    LB_TRY(hipGetLastError());
+    unsigned cnt[2];
+    LB_TRY(hipMemcpyAsync(cnt, &scalars[2], 8, hipMemcpyDeviceToHost, stream));
+    LB_TRY(hipStreamSynchronize(stream));
+    if(cnt[0] >= 2u && cnt[0] <= cap && cnt[1] + 1u == cnt[0])  // (a frontier too large for the host pass keeps the tree as built)
+    {
+      std::vector<TopEntry> fr(cnt[0]);
+      std::vector<int> ids(cnt[1]);
+      LB_TRY(hipMemcpyAsync(fr.data(), dFrontier, (size_t)cnt[0] * sizeof(TopEntry), hipMemcpyDeviceToHost, stream));
+      LB_TRY(hipMemcpyAsync(ids.data(), dTopIds, (size_t)cnt[1] * sizeof(int), hipMemcpyDeviceToHost, stream));
+      LB_TRY(hipStreamSynchronize(stream));
+      std::sort(ids.begin(), ids.end());  // the atomics hand out slots in any order: fix it (ids[0] = 0, the root)
+      std::sort(fr.begin(), fr.end(), [](const TopEntry& x, const TopEntry& y) { return x.ref < y.ref; });
+      std::vector<TopNode> top;
+      top.reserve(cnt[1]);
+      TopBuilder tb{fr, ids, top};
+      (void)tb.build(0, fr.size());
+      LB_TRY(hipMemcpyAsync(dTop, top.data(), top.size() * sizeof(TopNode), hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(k_top_apply, dim3(((unsigned)top.size() + B - 1) / B), dim3(B), 0, stream, (unsigned)top.size(), (const TopNode*)dTop, children, range,
+                         parentInternal, parentLeaf, nodeBox);
+      LB_TRY(hipGetLastError());
+      LB_TRY(hipStreamSynchronize(stream));  // `top` is read by the copy until here
+    }
+  }
   hipLaunchKernelGGL(k_emit, dim3(G), dim3(B), 0, stream, kLeaf, (int)T, order, (const float*)triBox, (const int2*)children, (const int2*)range,
                      (const float*)nodeBox, (float4*)out.nodes, (float*)&scalars[1]);
   hipLaunchKernelGGL(k_depth, dim3(G), dim3(B), 0, stream, kLeaf, (int)T, (const int2*)range, (const int*)parentInternal, (const int*)parentLeaf,

@@ -492,9 +492,10 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "scene is NULL");
   if(flags == 0)
     flags = VKRT_BUILD_DEFAULT;
-  const bool wantLbvh = (flags & VKRT_BUILD_LBVH_GPU) != 0, wantSah = (flags & VKRT_BUILD_SAH_HOST) != 0;
-  if(wantLbvh == wantSah)
-    return fail(VKRT_ERR_INVALID_ARGUMENT, "build_flags must select exactly one of VKRT_BUILD_LBVH_GPU / VKRT_BUILD_SAH_HOST");
+  const bool wantPloc = (flags & VKRT_BUILD_PLOC_GPU) != 0;
+  const bool wantLbvh = (flags & VKRT_BUILD_LBVH_GPU) != 0 || wantPloc, wantSah = (flags & VKRT_BUILD_SAH_HOST) != 0;
+  if(wantLbvh == wantSah || (wantPloc && (flags & VKRT_BUILD_LBVH_GPU) != 0) || (flags & ~7u) != 0)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "build_flags must select exactly one of VKRT_BUILD_LBVH_GPU / VKRT_BUILD_PLOC_GPU / VKRT_BUILD_SAH_HOST");
   int rc = setDevice(s);
   if(rc != VKRT_OK)
     return rc;
@@ -503,7 +504,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   freeAccel(s);
   const auto t0 = std::chrono::steady_clock::now();
   s->info = vkrt_accel_info{};
-  s->info.build_flags = wantLbvh ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
+  s->info.build_flags = wantPloc ? VKRT_BUILD_PLOC_GPU : wantLbvh ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
   s->wavefront = useWavefront(s);
 
   if(wantSah)
@@ -579,9 +580,10 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     // GPU radix-tree build (Morton codes, sort, Karras hierarchy, bottom-up fit).  For the trace-optimised layout the
     // binary tree keeps one triangle per leaf and is collapsed into wide8 nodes by the same SAH-optimal DP as the SAH
     // path -- on the device too (wide_collapse.hip); nothing but four statistics words comes back to the host.
-    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide);
+    // VKRT_BUILD_PLOC_GPU: same pipeline with the radix tree replaced by locally-ordered clustering (ploc.hip)
+    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide, wantPloc);
     if(rc != VKRT_OK)
-      return fail(rc, "LBVH build failed: %s", r.error.c_str());
+      return fail(rc, "%s build failed: %s", wantPloc ? "PLOC" : "LBVH", r.error.c_str());
     s->info.triangle_count = r.triCount;
     s->dev.triCount = r.triCount;
     if(wide && r.hasWide)

@@ -111,7 +111,7 @@ struct AppConfig
   bool hasCamera = false;
   Vec3 eye{0, 0, 15}, center{0, 0, 0}, up{0, 1, 0};
   float fov = 60.0f;
-  std::string build = "sah";
+  std::string build = "ploc";  // "ploc" (device, default) | "lbvh" (device, fastest build) | "sah" (host)
   std::string mode = "pathtrace";
   bool useShadows = true, useAO = true, useGI = false;  // hello_vulkan.cpp:913-915
   std::string output;

@@ -122,7 +122,7 @@ int main(int argc, char** argv)
     if(!helloVk.m_gltfScene.warnings.empty()) fprintf(stderr, "warning: %s\n", helloVk.m_gltfScene.warnings.c_str());
     helloVk.createOffscreenRender();                            // main.cpp:228
     helloVk.initRayTracing();                                   // main.cpp:235
-    helloVk.m_buildFlags = cfg.build == "lbvh" ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
+    helloVk.m_buildFlags = cfg.build == "lbvh" ? VKRT_BUILD_LBVH_GPU : cfg.build == "sah" ? VKRT_BUILD_SAH_HOST : VKRT_BUILD_PLOC_GPU;
     helloVk.createBottomLevelASGltf();                          // main.cpp:236
     helloVk.createTopLevelAsGltf();                             // main.cpp:237
     helloVk.m_pcRay.samples = cfg.samples;

@@ -115,7 +115,7 @@ def parse_config(text):
 
 
 def render_gltf(path, width, height, samples=1, depth=3, frames=1, seed0=0, eye=(0, 0, 15), center=(0, 0, 0), up=(0, 1, 0), fov=60.0,
-                build=abi.VKRT_BUILD_SAH_HOST, device=0):
+                build=abi.VKRT_BUILD_PLOC_GPU, device=0):
     img = np.zeros((height, width, 4), np.float32)
     e, c, p = (np.asarray(v, np.float32) for v in (eye, center, up))
     rc = lib().vkrt_host_render_gltf(os.fsencode(path), device, width, height, samples, depth, frames, seed0, e.ctypes.data,

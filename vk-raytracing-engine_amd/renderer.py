@@ -43,7 +43,7 @@ def whole_image_shard(width, height):
 
 
 class Renderer:
-    def __init__(self, flat, device=0, build="sah", options=None):
+    def __init__(self, flat, device=0, build="ploc", options=None):
         """options: {abi.VKRT_OPT_*: value} applied before the build (per-handle execution options, include/vkrt.h)."""
         import time
 
@@ -75,7 +75,7 @@ class Renderer:
         _check(self.lib.vkrt_reserve(self._h, C.byref(shard), C.c_void_p(stream.cuda_stream) if stream is not None else None), "vkrt_reserve")
 
     def build(self, kind="sah"):
-        flags = {"sah": abi.VKRT_BUILD_SAH_HOST, "lbvh": abi.VKRT_BUILD_LBVH_GPU}[kind]
+        flags = {"sah": abi.VKRT_BUILD_SAH_HOST, "lbvh": abi.VKRT_BUILD_LBVH_GPU, "ploc": abi.VKRT_BUILD_PLOC_GPU}[kind]
         _check(self.lib.vkrt_accel_build(self._h, flags, None), "vkrt_accel_build")
         self.build_kind = kind
 
