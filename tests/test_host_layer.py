@@ -151,7 +151,7 @@ def test_png_decoder(mode):
     rng = np.random.default_rng(1)
     if mode == "I;16":
         arr = rng.integers(0, 65536, (9, 13), dtype=np.uint16)
-        im = Image.fromarray(arr, "I;16")
+        im = Image.fromarray(arr)  # uint16 -> mode I;16
         want = np.stack([(arr >> 8).astype(np.uint8)] * 3 + [np.full_like(arr, 255, np.uint8)], -1)
     else:
         base = Image.fromarray(rng.integers(0, 256, (9, 13, 4), dtype=np.uint8), "RGBA")
@@ -291,9 +291,85 @@ def test_cli_hybrid_mode_matches_oracle(tmp_path, small_atrium):
     assert bad.any(axis=-1).mean() < 2e-3
 
 
-def test_jpeg_texture_through_sidecar_prepass(tmp_path):
-    """JPEG images reach the loader through tools/decode_textures.py (.rgba8 sidecar); the loader reports
-    without it the loader substitutes the reference's 1x1 white dummy."""
+def _jpeg_bytes(img, **kw):
+    import io
+
+    from PIL import Image
+
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def _picture(w, h, seed=1):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(xx / 7.0) * np.cos(yy / 11.0), 128 + 90 * np.cos(xx / 5.0 + yy / 9.0), (xx * 3 + yy * 5) % 256], -1)
+    img = img + rng.normal(0, 6, img.shape)
+    img[h // 3: h // 2 + 1, w // 4: w // 2 + 1] = [250, 10, 10]  # a saturated edge: chroma upsampling and clamping
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("size", [(64, 48), (37, 21), (1, 1), (8, 8), (17, 33), (200, 120)])
+def test_jpeg_decoder_against_pillow(size):
+    """host/jpeg_decode.cpp (the stb_image arithmetic the reference's texels come from, restated) against Pillow / libjpeg on
+    generated files: same Huffman / progressive decoding, so the two differ only where the standard leaves rounding open
+    (IDCT precision, the 3/4 - 1/4 upsampling filter's rounding, the fixed-point colour matrix): at most 3 levels."""
+    import io
+
+    from PIL import Image
+
+    w, h = size
+    src = _picture(w, h)
+    variants = {"444": dict(quality=90, subsampling=0), "420": dict(quality=90, subsampling=2), "422": dict(quality=90, subsampling=1),
+                "progressive420": dict(quality=90, subsampling=2, progressive=True), "progressive444": dict(quality=85, subsampling=0, progressive=True),
+                "q30": dict(quality=30, subsampling=2), "optimised": dict(quality=90, subsampling=2, optimize=True),
+                "restart": dict(quality=90, subsampling=2, restart_marker_blocks=3), "restart_rows_prog": dict(quality=80, subsampling=0, progressive=True, restart_marker_rows=1),
+                "q100": dict(quality=100, subsampling=0)}
+    for name, kw in variants.items():
+        data = _jpeg_bytes(src, **kw)
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)
+        got = host_py.decode_image(data)
+        assert got.shape == (h, w, 4) and (got[..., 3] == 255).all(), name
+        d = np.abs(got[..., :3].astype(int) - want)
+        if name == "422" and w > 2:
+            # stb_image's 2x horizontal filter weighs the second-to-last output column (3 * in[w-2] + in[w-1]) / 4 where the
+            # symmetric filter has (in[w-2] + 3 * in[w-1]) / 4; restated as published, so that column is not Pillow's
+            d[:, 2 * ((w + 1) // 2 - 1)] = 0
+        assert d.max() <= 3 and d.mean() < 0.5, (name, int(d.max()), float(d.mean()))
+    grey = _jpeg_bytes(src[..., 1], quality=92)
+    got = host_py.decode_image(grey)
+    want = np.asarray(Image.open(io.BytesIO(grey)).convert("L")).astype(int)
+    assert np.abs(got[..., 0].astype(int) - want).max() <= 1 and np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+
+
+def test_jpeg_decoder_refuses_what_it_does_not_read():
+    import io
+
+    from PIL import Image
+
+    cmyk = io.BytesIO()
+    Image.fromarray(_picture(16, 16)).convert("CMYK").save(cmyk, "JPEG")
+    with pytest.raises(ValueError, match="CMYK"):
+        host_py.decode_image(cmyk.getvalue())
+    good = _jpeg_bytes(_picture(32, 24), quality=90)
+    with pytest.raises(ValueError):
+        host_py.decode_image(good[:2] + b"\xff\xc9\x00\x0b\x08\x00\x10\x00\x10\x01\x01\x11\x00" + good[2:])  # SOF9: arithmetic coding
+    with pytest.raises(ValueError):
+        host_py.decode_image(good[:40])  # truncated before any scan
+    big = _jpeg_bytes(_picture(200, 120), quality=90)
+    cut = host_py.decode_image(big[: len(big) // 2])  # a truncated scan still yields an image (missing data reads as zeros), as stb_image does
+    assert cut.shape == (120, 200, 4)
+    with pytest.raises(ValueError):
+        host_py.decode_image(b"\x00" * 64)
+
+
+def test_jpeg_textures_load_natively_and_sidecar_wins(tmp_path):
+    """SURVEY 8f row 2 / VERDICT r01 missing 6: JPEG images (external file, GLB-embedded bufferView) decode in the C++ loader;
+    a .rgba8 sidecar from tools/decode_textures.py still takes precedence; an image the decoder refuses becomes the reference's
+    1x1 white dummy (hello_vulkan.cpp:487-491)."""
+    import io
+
     from PIL import Image
 
     import decode_textures
@@ -301,26 +377,50 @@ def test_jpeg_texture_through_sidecar_prepass(tmp_path):
     rng = np.random.default_rng(5)
     img = np.kron(rng.integers(0, 256, (4, 6, 3), dtype=np.uint8), np.ones((8, 8, 1), np.uint8))  # blocky: JPEG-friendly
     Image.fromarray(img, "RGB").save(tmp_path / "albedo.jpg", quality=95)
+    Image.fromarray(img, "RGB").convert("CMYK").save(tmp_path / "print.jpg")
     pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     (tmp_path / "tri.bin").write_bytes(pos.tobytes() + np.array([0, 1, 2], np.uint32).tobytes())
     doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
            "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]}],
-           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
-           "textures": [{"source": 0}], "images": [{"uri": "albedo.jpg"}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}, "metallicRoughnessTexture": {"index": 1}}}],
+           "textures": [{"source": 0}, {"source": 1}], "images": [{"uri": "albedo.jpg"}, {"uri": "print.jpg"}],
            "buffers": [{"uri": "tri.bin", "byteLength": 48}],
            "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 12}],
            "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3", "min": [0, 0, 0], "max": [1, 1, 0]},
                          {"bufferView": 1, "componentType": 5125, "count": 3, "type": "SCALAR"}]}
     path = tmp_path / "tri.gltf"
     path.write_text(json.dumps(doc))
-    flat = host_py.load_gltf(str(path))  # no sidecar yet: the reference's rule for an undecodable image, 1x1 white (hello_vulkan.cpp:487-491)
-    assert flat.textures[0]["rgba8"].shape == (1, 1, 4) and np.all(flat.textures[0]["rgba8"] == 255)
-    assert decode_textures.main([str(path)]) == 0
-    flat = host_py.load_gltf(str(path))
     want = np.array(Image.open(tmp_path / "albedo.jpg").convert("RGBA"), np.uint8)
-    assert len(flat.textures) == 1 and flat.textures[0]["is_srgb"]  # base colour => sRGB (hello_vulkan.cpp:417-443)
-    assert np.array_equal(flat.textures[0]["rgba8"], want)
-    assert np.abs(want[..., :3].astype(int) - img.astype(int)).mean() < 16  # it really is the picture (JPEG is lossy at block edges)
+    flat = host_py.load_gltf(str(path))
+    assert len(flat.textures) == 2 and flat.textures[0]["is_srgb"] and not flat.textures[1]["is_srgb"]  # hello_vulkan.cpp:417-443
+    native = flat.textures[0]["rgba8"]
+    assert native.shape == want.shape and np.abs(native.astype(int) - want.astype(int)).max() <= 3
+    assert np.abs(native[..., :3].astype(int) - img.astype(int)).mean() < 16  # it really is the picture
+    assert flat.textures[1]["rgba8"].shape == (1, 1, 4) and np.all(flat.textures[1]["rgba8"] == 255)  # CMYK: refused -> white dummy
+    assert decode_textures.main([str(path)]) == 0 and not (tmp_path / "albedo.jpg.rgba8").exists()  # nothing the loader cannot read... but CMYK is by extension a .jpg
+    assert decode_textures.main([str(path), "--all"]) == 0
+    flat = host_py.load_gltf(str(path))
+    assert np.array_equal(flat.textures[0]["rgba8"], want)  # the sidecar (Pillow's decode) wins
+    assert flat.textures[1]["rgba8"].shape == (32, 48, 4)   # and rescues the CMYK file
+
+    # the same JPEG embedded in a .glb (bufferView image)
+    import struct
+
+    jpg = (tmp_path / "albedo.jpg").read_bytes()
+    geo = pos.tobytes() + np.array([0, 1, 2], np.uint32).tobytes()
+    blob = geo + jpg + b"\x00" * (-len(jpg) % 4)
+    doc["images"] = [{"bufferView": 2, "mimeType": "image/jpeg"}]
+    doc["textures"] = [{"source": 0}]
+    doc["materials"] = [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]
+    doc["buffers"] = [{"byteLength": len(blob)}]
+    doc["bufferViews"].append({"buffer": 0, "byteOffset": 48, "byteLength": len(jpg)})
+    js = json.dumps(doc).encode()
+    js += b" " * (-len(js) % 4)
+    glb = struct.pack("<III", 0x46546C67, 2, 12 + 8 + len(js) + 8 + len(blob)) + struct.pack("<II", len(js), 0x4E4F534A) + js + \
+        struct.pack("<II", len(blob), 0x004E4942) + blob
+    (tmp_path / "tri.glb").write_bytes(glb)
+    flat = host_py.load_gltf(str(tmp_path / "tri.glb"))
+    assert np.array_equal(flat.textures[0]["rgba8"], native)
 
 
 def test_png_writer_round_trip(tmp_path):

@@ -1,14 +1,15 @@
-"""Texture pre-pass for glTF scenes whose images the native loader cannot decode (JPEG, interlaced PNG, ...).
+"""Texture pre-pass for glTF scenes whose images the native loader cannot decode (CMYK / arithmetic-coded JPEG, interlaced
+PNG, other formats), or whose decode should be pinned to Pillow's.
 
-The C++ host layer (vk-raytracing-engine_amd/host/gltf_loader.cpp: decodeImageFile) decodes PNG itself and otherwise looks
-for `<image uri>.rgba8` next to the image: two little-endian u32 (width, height) followed by width*height RGBA8 texels,
+The C++ host layer (vk-raytracing-engine_amd/host/gltf_loader.cpp: decodeImageFile) decodes PNG and JPEG itself
+(jpeg_decode.cpp) and first looks for `<image uri>.rgba8` next to the image: two little-endian u32 (width, height) followed by width*height RGBA8 texels,
 rows top to bottom -- the layout stb_image hands the reference (hello_vulkan.cpp:482-485, 4 channels forced).  This tool
 writes those sidecars with PIL.  Usage:
 
     python tools/decode_textures.py scene.gltf [--all] [--force]
 
-By default only images that are not PNG get a sidecar; --all converts every external image (the sidecar wins over the
-native PNG decoder); --force overwrites existing sidecars.  Embedded (bufferView / data-URI) images are not handled:
+By default only images that are neither PNG nor JPEG get a sidecar; --all converts every external image (the sidecar wins over
+the native decoders); --force overwrites existing sidecars.  Embedded (bufferView / data-URI) images are not handled:
 export the scene with external images first.
 """
 import argparse
@@ -35,7 +36,7 @@ def write_sidecar(src, dst):
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("gltf")
-    ap.add_argument("--all", action="store_true", help="also convert PNG images")
+    ap.add_argument("--all", action="store_true", help="also convert PNG and JPEG images")
     ap.add_argument("--force", action="store_true", help="overwrite existing sidecars")
     a = ap.parse_args(argv)
     if a.gltf.lower().endswith(".glb"):
@@ -49,7 +50,7 @@ def main(argv=None):
             print(f"image {i}: embedded, skipped")
             continue
         path = os.path.join(base, urllib.parse.unquote(uri))
-        if not a.all and path.lower().endswith(".png"):
+        if not a.all and path.lower().endswith((".png", ".jpg", ".jpeg")):
             continue
         dst = path + ".rgba8"
         if os.path.exists(dst) and not a.force:

@@ -126,6 +126,17 @@ int vkrt_host_decode_png(const uint8_t* data, uint64_t size, uint32_t* wh, uint8
   return 0;
 }
 
+/* PNG or JPEG by signature */
+int vkrt_host_decode_image(const uint8_t* data, uint64_t size, uint32_t* wh, uint8_t* rgbaOut, uint64_t cap)
+{
+  TextureImage t;
+  std::string why;
+  if(!decodeImageMemory(data, (size_t)size, t, why)) { g_err = why; return 1; }
+  wh[0] = t.width; wh[1] = t.height;
+  if(rgbaOut && cap >= t.rgba.size()) memcpy(rgbaOut, t.rgba.data(), t.rgba.size());
+  return 0;
+}
+
 int vkrt_host_write_png(const char* path, const float* displayRgba, int w, int h)
 {
   try

@@ -402,9 +402,16 @@ bool decodePngMemory(const uint8_t* data, size_t size, TextureImage& out, std::s
   return true;
 }
 
+bool decodeImageMemory(const uint8_t* data, size_t size, TextureImage& out, std::string& why)
+{
+  if(size >= 2 && data[0] == 0xff && data[1] == 0xd8)
+    return decodeJpegMemory(data, size, out, why);
+  return decodePngMemory(data, size, out, why);
+}
+
 bool decodeImageFile(const std::string& path, TextureImage& out, std::string& why)
 {
-  // raw sidecar first (JPEG and anything else goes through tools/decode_textures.py)
+  // a raw sidecar wins when present (tools/decode_textures.py: formats this loader does not read, or a pinned decode)
   {
     std::ifstream f(path + ".rgba8", std::ios::binary);
     if(f)
@@ -425,7 +432,7 @@ bool decodeImageFile(const std::string& path, TextureImage& out, std::string& wh
   }
   std::vector<uint8_t> d;
   try { d = readFile(path); } catch(const std::exception& e) { why = e.what(); return false; }
-  return decodePngMemory(d.data(), d.size(), out, why);
+  return decodeImageMemory(d.data(), d.size(), out, why);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -681,7 +688,7 @@ GltfScene loadGltf(const std::string& filename)
         if(uri.compare(0, 5, "data:") == 0)
         {
           const std::vector<uint8_t> d = base64Decode(uri, uri.find(',') + 1);
-          ok[i] = decodePngMemory(d.data(), d.size(), decoded[i], why);
+          ok[i] = decodeImageMemory(d.data(), d.size(), decoded[i], why);
         }
         else
           ok[i] = decodeImageFile(doc.base + "/" + uri, decoded[i], why);
@@ -692,7 +699,7 @@ GltfScene loadGltf(const std::string& filename)
         const std::vector<uint8_t>& buf = doc.buffers.at((size_t)bv["buffer"].integer());
         const size_t off = (size_t)bv["byteOffset"].integer(0), len = (size_t)bv["byteLength"].integer(0);
         if(off + len <= buf.size())
-          ok[i] = decodePngMemory(buf.data() + off, len, decoded[i], why);
+          ok[i] = decodeImageMemory(buf.data() + off, len, decoded[i], why);
       }
       if(!ok[i])
       {  // addDefaultTexture: 1x1 white (hello_vulkan.cpp:458-472,487-491)

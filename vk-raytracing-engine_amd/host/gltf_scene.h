@@ -78,5 +78,9 @@ GltfScene loadGltf(const std::string& filename);
 // tools/decode_textures.py.  Returns false when the image cannot be decoded.
 bool decodeImageFile(const std::string& path, TextureImage& out, std::string& why);
 bool decodePngMemory(const uint8_t* data, size_t size, TextureImage& out, std::string& why);
+// baseline / extended-sequential / progressive Huffman JPEG, 8-bit, grey or YCbCr (jpeg_decode.cpp)
+bool decodeJpegMemory(const uint8_t* data, size_t size, TextureImage& out, std::string& why);
+// by signature: PNG or JPEG
+bool decodeImageMemory(const uint8_t* data, size_t size, TextureImage& out, std::string& why);
 
 }  // namespace vkrt_host

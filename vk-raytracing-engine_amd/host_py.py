@@ -34,6 +34,8 @@ def lib():
         L.vkrt_host_render_gltf.restype = C.c_int
         L.vkrt_host_decode_png.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
         L.vkrt_host_decode_png.restype = C.c_int
+        L.vkrt_host_decode_image.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.vkrt_host_decode_image.restype = C.c_int
         L.vkrt_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
         L.vkrt_host_write_png.restype = C.c_int
         L.vkrt_host_strip_rows.argtypes = [C.c_uint32] * 4
@@ -132,6 +134,17 @@ def decode_png(data):
         raise ValueError(lib().vkrt_host_last_error().decode())
     out = np.zeros((int(wh[1]), int(wh[0]), 4), np.uint8)
     lib().vkrt_host_decode_png(buf.ctypes.data, buf.size, wh.ctypes.data, out.ctypes.data, out.size)
+    return out
+
+
+def decode_image(data):
+    """PNG or JPEG bytes -> (H, W, 4) uint8 through the C++ host's decoders (the texels the loader hands to the library)."""
+    wh = np.zeros(2, np.uint32)
+    buf = np.frombuffer(data, np.uint8)
+    if lib().vkrt_host_decode_image(buf.ctypes.data, buf.size, wh.ctypes.data, None, 0) != 0:
+        raise ValueError(lib().vkrt_host_last_error().decode())
+    out = np.zeros((int(wh[1]), int(wh[0]), 4), np.uint8)
+    lib().vkrt_host_decode_image(buf.ctypes.data, buf.size, wh.ctypes.data, out.ctypes.data, out.size)
     return out
 
 
