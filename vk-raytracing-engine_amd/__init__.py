@@ -10,6 +10,8 @@ import os
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libvkrt.so")
+if os.environ.get("VKRT_LIB"):  # test hook: A/B of two builds of the library from one tree (tools/probe_variants.sh)
+    LIB_PATH = os.path.abspath(os.environ["VKRT_LIB"])
 HOST_LIB_PATH = os.path.join(PKG_DIR, "libvkrt_host.so")
 
 from . import abi  # noqa: E402,F401
