@@ -275,7 +275,7 @@ def main():
                                       "guide's measured L2 gather rate"},
                 "frame": {"ms": float(np.mean(frame_ms)), "traverse_ms": float(np.mean(trav_ms))},
                 "note": "kernel_ms = mean duration of un-overlapped k_wf_traverse launches (timing pass, one sub-frame); value is measured with the "
-                        "default two-sub-frame pipeline.  Bytes are what the kernel's algorithm fetches from its own data structure, counted by the "
+                        "default three-sub-frame pipeline.  Bytes are what the kernel's algorithm fetches from its own data structure, counted by the "
                         "kernel; they are served from L2 / Infinity Cache (traffic), so HBM does not bind -- VALU issue does (issue).",
             }
             pm = fresh_profile(os.path.join(ROOT, "profiles", "pmc_traffic.json"), key)
