@@ -10,7 +10,7 @@ import atrium, camera_np
 W, H = 1920, 1080
 flat, info = atrium.build_atrium(262144, seed=1)
 cam = uniforms_from_matrices(*camera_np.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA))
-r = Renderer(flat, device=0, build=os.environ.get("BUILD", "sah"))
+r = Renderer(flat, device=0, build=os.environ.get("BUILD", "ploc"))
 def timed(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -19,7 +19,12 @@ def timed(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return out, e0.elapsed_time(e1) / n
 g, ms_g = timed(lambda: r.gbuffer_raycast(cam, W, H, lights_count=8))
-print(json.dumps({"kernel": "k_gbuffer", "ms": round(ms_g, 3), "Mpixels_s": round(W * H / ms_g / 1e3, 1)}))
+print(json.dumps({"kernel": "k_gbuffer", "texture_lod": "implicit (mips, anisotropy 4)", "ms": round(ms_g, 3), "Mpixels_s": round(W * H / ms_g / 1e3, 1)}))
+from vkrt_amd import abi
+r.set_option(abi.VKRT_OPT_GBUFFER_MIPS, 0)
+_, ms_0 = timed(lambda: r.gbuffer_raycast(cam, W, H, lights_count=8))
+r.set_option(abi.VKRT_OPT_GBUFFER_MIPS, 1)
+print(json.dumps({"kernel": "k_gbuffer", "texture_lod": "0", "ms": round(ms_0, 3), "Mpixels_s": round(W * H / ms_0 / 1e3, 1)}))
 for sh, ao, gi in ((1, 0, 0), (1, 1, 0), (1, 1, 1)):
     pc = make_push_constants(samples=1, depth=8, frame=0, lights_count=8)
     pc.useShadows, pc.useAO, pc.useGI = sh, ao, gi
