@@ -364,6 +364,48 @@ def test_jpeg_decoder_refuses_what_it_does_not_read():
         host_py.decode_image(b"\x00" * 64)
 
 
+def test_image_decoders_survive_corrupt_input():
+    """Mutated PNG / JPEG files either decode or are refused with a message (the decoders were also run under ASan + UBSan on
+    100 k such files): no crash, no allocation driven by a forged header."""
+    import io
+    import struct
+
+    from PIL import Image
+
+    rng = np.random.default_rng(9)
+    seeds = [_jpeg_bytes(_picture(40, 24), quality=80, subsampling=2), _jpeg_bytes(_picture(40, 24), quality=80, subsampling=0, progressive=True)]
+    b = io.BytesIO()
+    Image.fromarray(_picture(31, 17)).save(b, "PNG")
+    seeds.append(b.getvalue())
+    decoded = refused = 0
+    for data in seeds:
+        for _ in range(150):
+            m = bytearray(data)
+            for _k in range(int(rng.integers(1, 6))):
+                pos = int(rng.integers(0, len(m)))
+                kind = int(rng.integers(0, 4))
+                if kind == 0:
+                    m[pos] = int(rng.integers(0, 256))
+                elif kind == 1:
+                    m[pos] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 2:
+                    del m[pos + 1:]
+                else:
+                    m[pos] = 0xFF
+            try:
+                img = host_py.decode_image(bytes(m))
+                assert img.ndim == 3 and img.shape[2] == 4
+                decoded += 1
+            except ValueError:
+                refused += 1
+    assert decoded > 20 and refused > 20
+    # a PNG header promising 60000 x 60000 texels over a few bytes of data
+    png = bytearray(seeds[2])
+    png[16:24] = struct.pack(">II", 60000, 60000)
+    with pytest.raises(ValueError):
+        host_py.decode_image(bytes(png))
+
+
 def test_jpeg_textures_load_natively_and_sidecar_wins(tmp_path):
     """SURVEY 8f row 2 / VERDICT r01 missing 6: JPEG images (external file, GLB-embedded bufferView) decode in the C++ loader;
     a .rgba8 sidecar from tools/decode_textures.py still takes precedence; an image the decoder refuses becomes the reference's

@@ -323,6 +323,7 @@ bool decodePngMemory(const uint8_t* data, size_t size, TextureImage& out, std::s
     i += 12 + (size_t)len;
   }
   if(w == 0 || h == 0) { why = "missing IHDR"; return false; }
+  if(w > 65535u || h > 65535u || (uint64_t)w * h > (1ull << 28)) { why = "PNG larger than the texture limits (65535 per side, 2^28 texels)"; return false; }
   if(interlace) { why = "interlaced PNG not supported"; return false; }
   int channels;
   switch(ctype)
@@ -338,6 +339,8 @@ bool decodePngMemory(const uint8_t* data, size_t size, TextureImage& out, std::s
   const size_t bitsPerPixel = (size_t)channels * depth;
   const size_t rowBytes = (w * bitsPerPixel + 7) / 8;
   const size_t bpp = std::max<size_t>(1, bitsPerPixel / 8);
+  // (deflate expands at most ~1032 : 1: a header that promises more than the data can hold is corrupt -- do not allocate for it)
+  if((rowBytes + 1) * (size_t)h > idat.size() * 1040 + 1024) { why = "PNG data too short for its header"; return false; }
   std::vector<uint8_t> raw((rowBytes + 1) * (size_t)h);
   uLongf rawLen = (uLongf)raw.size();
   if(uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) { why = "zlib inflate failed"; return false; }

@@ -200,8 +200,8 @@ struct Decoder
     if(t < 0 || t > 15) return fail("bad DC code");
     memset(data, 0, 64 * sizeof(short));
     const int diff = t ? receiveExtend(t) : 0;
-    c.dcPred += diff;
-    data[0] = (short)(c.dcPred * dq[0]);
+    c.dcPred = (int)((unsigned)c.dcPred + (unsigned)diff);  // (wraps on corrupt data instead of overflowing)
+    data[0] = (short)((unsigned)c.dcPred * dq[0]);
     int k = 1;
     do
     {
@@ -231,8 +231,8 @@ struct Decoder
       const int t = decodeSymbol(dc[c.hd]);
       if(t < 0 || t > 15) return fail("bad DC code");
       const int diff = t ? receiveExtend(t) : 0;
-      c.dcPred += diff;
-      data[0] = (short)(c.dcPred * (1 << succLow));
+      c.dcPred = (int)((unsigned)c.dcPred + (unsigned)diff);
+      data[0] = (short)((unsigned)c.dcPred << succLow);
     }
     else if(getBit())
       data[0] = (short)(data[0] + (short)(1 << succLow));
@@ -336,13 +336,16 @@ struct Decoder
 
   // ---- inverse DCT (see the header) --------------------------------------------------------------------------------------
   static inline int f2f(double x) { return (int)(x * 4096 + 0.5); }
-  static inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+  static inline uint8_t clamp8(long long x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+  // (64-bit intermediates: the values of a well-formed file fit 32 bits with room to spare; a corrupt one must not run into
+  //  signed overflow)
+  typedef long long wide;
   struct Idct1D
   {
-    int x0, x1, x2, x3, t0, t1, t2, t3;
-    Idct1D(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+    wide x0, x1, x2, x3, t0, t1, t2, t3;
+    Idct1D(wide s0, wide s1, wide s2, wide s3, wide s4, wide s5, wide s6, wide s7)
     {
-      int p1, p2, p3, p4, p5;
+      wide p1, p2, p3, p4, p5;
       p2 = s2; p3 = s6;
       p1 = (p2 + p3) * f2f(0.5411961);
       t2 = p1 + p3 * f2f(-1.847759065);
@@ -367,20 +370,20 @@ struct Decoder
   };
   static void idctBlock(uint8_t* out, int stride, const short* d)
   {
-    int val[64];
+    wide val[64];
     for(int i = 0; i < 8; i++)
     {
       const short* c = d + i;
-      int* v = val + i;
+      wide* v = val + i;
       if(c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0)
       {
-        const int dcterm = c[0] * 4;
+        const wide dcterm = c[0] * 4;
         v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
       }
       else
       {
         Idct1D k(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
-        const int x0 = k.x0 + 512, x1 = k.x1 + 512, x2 = k.x2 + 512, x3 = k.x3 + 512;
+        const wide x0 = k.x0 + 512, x1 = k.x1 + 512, x2 = k.x2 + 512, x3 = k.x3 + 512;
         v[0] = (x0 + k.t3) >> 10; v[56] = (x0 - k.t3) >> 10;
         v[8] = (x1 + k.t2) >> 10; v[48] = (x1 - k.t2) >> 10;
         v[16] = (x2 + k.t1) >> 10; v[40] = (x2 - k.t1) >> 10;
@@ -389,11 +392,11 @@ struct Decoder
     }
     for(int i = 0; i < 8; i++)
     {
-      const int* v = val + 8 * i;
+      const wide* v = val + 8 * i;
       uint8_t* o = out + (size_t)i * stride;
       Idct1D k(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-      const int bias = 65536 + (128 << 17);
-      const int x0 = k.x0 + bias, x1 = k.x1 + bias, x2 = k.x2 + bias, x3 = k.x3 + bias;
+      const wide bias = 65536 + (128 << 17);
+      const wide x0 = k.x0 + bias, x1 = k.x1 + bias, x2 = k.x2 + bias, x3 = k.x3 + bias;
       o[0] = clamp8((x0 + k.t3) >> 17); o[7] = clamp8((x0 - k.t3) >> 17);
       o[1] = clamp8((x1 + k.t2) >> 17); o[6] = clamp8((x1 - k.t2) >> 17);
       o[2] = clamp8((x2 + k.t1) >> 17); o[5] = clamp8((x2 - k.t1) >> 17);
