@@ -8,8 +8,10 @@
 //
 //   clusters = the triangles in Morton order (cluster = node reference + box + triangle count)
 //   repeat until one cluster is left:
-//     k_ploc_nn      every cluster i picks, among the clusters within RADIUS positions of it, the one whose union with i
-//                    has the smallest surface area (boxes of a workgroup's window staged in LDS)
+//     k_ploc_nn      every cluster i picks, among the clusters within RADIUS positions of it, the one it is cheapest to merge
+//                    with (boxes of a workgroup's window staged in LDS).  Cost of a merge = what it adds to the tree's SAH
+//                    sum: area(union) * (n_i + n_j) - area_i * n_i - area_j * n_j (n = triangles below).  The paper's
+//                    distance, area(union) alone, builds trees that trace 1 % slower here (profiles/r02_experiments.md #67)
 //     k_ploc_count   mutual picks merge: the lower position of a pair becomes the new node, the higher one disappears;
 //                    per-workgroup counts of surviving clusters and of merges
 //     k_ploc_scan    one workgroup: exclusive scan of the per-workgroup counts
@@ -64,9 +66,10 @@ VKRT_DEV float unionArea(const float* a, const float* b)  // a, b: lo[3] hi[3]
   return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int nc, int radius, const PlocCluster* __restrict__ c, int* __restrict__ nn)
+__global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int nc, int radius, int metric, const PlocCluster* __restrict__ c, int* __restrict__ nn)
 {
   __shared__ float box[(PLOC_BLOCK + 2 * PLOC_MAX_RADIUS) * 6];
+  __shared__ float own[(PLOC_BLOCK + 2 * PLOC_MAX_RADIUS) * 2];  // own area, triangle count
   const int first = (int)(blockIdx.x * PLOC_BLOCK) - radius;  // position of box[0]
   for(int k = (int)threadIdx.x; k < PLOC_BLOCK + 2 * radius; k += PLOC_BLOCK)
   {
@@ -76,6 +79,8 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int nc, int radius, cons
       const PlocCluster q = c[p];
       box[6 * k + 0] = q.lo[0]; box[6 * k + 1] = q.lo[1]; box[6 * k + 2] = q.lo[2];
       box[6 * k + 3] = q.hi[0]; box[6 * k + 4] = q.hi[1]; box[6 * k + 5] = q.hi[2];
+      own[2 * k] = unionArea(&box[6 * k], &box[6 * k]);
+      own[2 * k + 1] = (float)q.count;
     }
   }
   __syncthreads();
@@ -83,12 +88,21 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int nc, int radius, cons
   if(i >= nc)
     return;
   const float* mine = &box[6 * (i - first)];
+  const float myCount = own[2 * (i - first) + 1];
+  // (the terms that only depend on i are the same for all its candidates and left out; the full cost is symmetric in i and j,
+  //  which the mutual-pair argument above needs)
+  auto dist = [&](int j) {
+    const float u = unionArea(mine, &box[6 * (j - first)]);
+    if(metric == 0) return u;                              // Meister & Bittner: area of the union
+    if(metric == 1) return u - own[2 * (j - first)];       // area increase
+    return u * (myCount + own[2 * (j - first) + 1]) - own[2 * (j - first)] * own[2 * (j - first) + 1];  // SAH increase (default)
+  };
   float best = INFINITY;
   int pick = -1;
   const int partner = i ^ 1;
   if(partner < nc)
   {
-    best = unionArea(mine, &box[6 * (partner - first)]);
+    best = dist(partner);
     pick = partner;
   }
   const int j0 = max(0, i - radius), j1 = min(nc - 1, i + radius);
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int nc, int radius, cons
   {
     if(j == i || j == partner)
       continue;
-    const float d = unionArea(mine, &box[6 * (j - first)]);
+    const float d = dist(j);
     if(d < best || pick < 0)
     {
       best = d;
@@ -235,6 +249,9 @@ int ploc_cluster_device(uint32_t T, const unsigned* order, const float* triBox, 
   int radius = 16;
   if(const char* e = getenv("VKRT_PLOC_RADIUS"))  // test hook: search window of the clustering (1..32)
     radius = std::max(1, std::min(PLOC_MAX_RADIUS, atoi(e)));
+  int metric = 2;
+  if(const char* e = getenv("VKRT_PLOC_METRIC"))  // test hook: merge cost (see k_ploc_nn)
+    metric = atoi(e);
   const unsigned maxBlocks = (T + PLOC_BLOCK - 1) / PLOC_BLOCK;
   const size_t clusterBytes = (size_t)T * sizeof(PlocCluster);
   const size_t bytes = 2 * clusterBytes + (size_t)T * 4 + (size_t)maxBlocks * 8 + 64;
@@ -262,7 +279,7 @@ int ploc_cluster_device(uint32_t T, const unsigned* order, const float* triBox, 
   while(nc > 1)
   {
     const unsigned blocks = (nc + PLOC_BLOCK - 1) / PLOC_BLOCK;
-    hipLaunchKernelGGL(k_ploc_nn, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, radius, (const PlocCluster*)cl[cur], nn);
+    hipLaunchKernelGGL(k_ploc_nn, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, radius, metric, (const PlocCluster*)cl[cur], nn);
     hipLaunchKernelGGL(k_ploc_count, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, (const int*)nn, blockCounts);
     hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, stream, blocks, blockCounts, totals);
     hipLaunchKernelGGL(k_ploc_apply, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, nextId, (const int*)nn, (const PlocCluster*)cl[cur],
