@@ -146,7 +146,17 @@ def test_gpu_hybrid_textured_atrium_and_toggles():
         out = r.hybrid_trace(pc, cam, W, H, g, seed=5).cpu().numpy()
         ref, _ = orc.hybrid(pc, cam, W, H, gnp, seed=5)
         assert _mismatch(out, ref) < 2e-4, (sh, ao, gi)
+    # the wave-synchronous kernel with work sharing (default) and the one-lane-one-walk kernel are the same function of the pixel
+    from vkrt_amd import abi
+    pc = make_push_constants(samples=1, depth=6, frame=0, lights_count=len(flat.lights))
+    pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+    shared = r.hybrid_trace(pc, cam, W, H, g, seed=11).cpu().numpy()
     r.close()
+    for opts in ({abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_BVH_LAYOUT: 0}):
+        r2 = Renderer(flat, device=0, build="sah", options=opts)
+        alone = r2.hybrid_trace(pc, cam, W, H, g, seed=11).cpu().numpy()
+        r2.close()
+        assert np.array_equal(shared.view(np.uint32), alone.view(np.uint32)), opts
 
 
 # ---- NRD / REBLUR front-end planes (gltf.glsl:156-273) -------------------------------------------------

@@ -6,7 +6,8 @@
 //   k_hybrid   raytraceHybrid.rgen:50-303 (1 shadow ray, 4 AO rays, optional GI path reusing the path tracer's
 //              closest-hit / miss shaders), accumulating into the rgba32f accumulation image (:36-48).
 //   k_post     post.frag:36-58 composite (raster.rgb * rt.a + rt.rgb) and gamma 1/2.2.
-// One thread per pixel; traversal and shading are the path tracer's (traverse*.h, shade.h).
+// One thread per pixel; traversal and shading are the path tracer's (traverse*.h, shade.h).  With the wide layout k_hybrid runs one
+// wave per 8x8 tile in lockstep so that its rays use the work-sharing traversal (traverse_share.h).
 #include <hip/hip_runtime.h>
 
 #include "device_math.h"
@@ -16,6 +17,7 @@
 #include "shade.h"
 #include "traverse.h"
 #include "traverse_wide.h"
+#include "traverse_share.h"
 
 #define HY_BLOCK 256
 
@@ -281,77 +283,141 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 5, red);
 }
 
-template <bool WIDE>
-__global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
+// One ray of every lane that has one.  SHARE: the 64 lanes of the (one-wave) workgroup walk together and lanes without a ray,
+// or done with theirs, take over pending subtrees of the others (traverse_share.h) -- the call must then be reached by all 64 lanes
+// (workgroup-uniform control flow around it).  Otherwise every lane walks alone.
+template <bool WIDE, bool SHARE>
+VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int* shareLds, RayHit& hit, TravCount& tc)
+{
+  if(SHARE)
+  {
+    uint2* stk = ((uint2*)lds) + threadIdx.x;
+    if(!valid)
+    {
+      o = mk3(0.0f); d = mk3(1.0f, 0.0f, 0.0f); tmax = 0.0f;
+    }
+    if(anyHit)
+      traverse_wide8_share<false, true>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
+    else
+      traverse_wide8_share<false, false>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
+    if(!valid)
+      hit.slot = -1;
+  }
+  else
+  {
+    hit.slot = -1;
+    if(valid)
+      traverse_any<false, WIDE>(sc, o, d, tmin, tmax, anyHit, lds, (int)threadIdx.x, (int)blockDim.x, hit, tc);
+  }
+}
+
+// SHARE (the default with the wide layout): one wave per workgroup = one 8x8 tile, every loop and branch around a trace is
+// taken by the whole wave as long as any of its pixels needs it.  The per-pixel sequence of random numbers, rays and float
+// operations is that of rgen either way; tests/test_hybrid.py compares the two instantiations with each other and the oracle.
+template <bool WIDE, bool SHARE>
+__global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridParams H)
 {
   extern __shared__ int lds_stack[];
+  __shared__ int shareLds[SHARE ? VKRT_SHARE_LDS_WORDS : 1];
   const TraceParams& P = H.T;
   const DevScene& sc = P.sc;
-  uint32_t x, y, lrow;
+  uint32_t x = 0, y = 0, lrow = 0;
   unsigned nClosest = 0, nShadow = 0, nPixels = 0;
   TravCount tc;
   __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
   st.lut = ldsTexelLut(P.sc, lut);
-  if(pixelOf(P, x, y, lrow))
+  const bool inImage = pixelOf(P, x, y, lrow);
+  auto anyLane = [](bool c) { return SHARE ? __any(c) != 0 : c; };
+  Payload prd;
+  prd.seed = 0u;
+  prd.isSpecular = false; prd.lightDist = 0.0f; prd.shadowRayDir = mk3(0.0f); prd.depth = 0;
+  prd.hitValue = mk3(0.0f); prd.weight = mk3(0.0f); prd.rayOrigin = mk3(0.0f); prd.rayDirection = mk3(0.0f);
+  float4 color = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+  size_t p = 0;
+  f3 worldPos = mk3(0.0f), worldNrm = mk3(0.0f), albedo = mk3(0.0f);
+  float roughness = 0.0f, metalness = 0.0f;
+  bool shaded = false;
+  if(inImage)
   {
     nPixels = 1;
-    const size_t p = (size_t)lrow * P.fullW + x;
-    Payload prd;
+    p = (size_t)lrow * P.fullW + x;
     prd.seed = tea((P.flags & 1u) ? (y * P.fullW + x) : (y * x + x), P.seed);  // rgen:55
-    prd.isSpecular = false; prd.lightDist = 0.0f; prd.shadowRayDir = mk3(0.0f); prd.depth = 0;
-    prd.hitValue = mk3(0.0f); prd.weight = mk3(0.0f); prd.rayOrigin = mk3(0.0f); prd.rayDirection = mk3(0.0f);
-    float4 color = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     const float4 pixelImg = H.color[p], pixelPos = H.position[p], pixelNorm = H.normal[p];
     const float2 rm = H.rough[p];
-    const f3 worldPos = mk3(pixelPos.x, pixelPos.y, pixelPos.z), worldNrm = mk3(pixelNorm.x, pixelNorm.y, pixelNorm.z);
-    const bool shaded = !(worldPos.x == 0.0f && worldPos.y == 0.0f && worldPos.z == 0.0f && worldNrm.x == 0.0f && worldNrm.y == 0.0f &&
-                          worldNrm.z == 0.0f);  // rgen:67
-    if(shaded)
+    worldPos = mk3(pixelPos.x, pixelPos.y, pixelPos.z); worldNrm = mk3(pixelNorm.x, pixelNorm.y, pixelNorm.z);
+    shaded = !(worldPos.x == 0.0f && worldPos.y == 0.0f && worldPos.z == 0.0f && worldNrm.x == 0.0f && worldNrm.y == 0.0f &&
+               worldNrm.z == 0.0f);  // rgen:67
+    albedo = mk3(pixelImg.w, pixelPos.w, pixelNorm.w);
+    roughness = rm.x; metalness = rm.y;
+  }
+  if(anyLane(shaded))
+  {
+    RayHit hit;
+    if(P.pc.useShadows == 1)  // rgen:81-131
     {
-      const f3 albedo = mk3(pixelImg.w, pixelPos.w, pixelNorm.w);
-      const float roughness = rm.x, metalness = rm.y;
-      RayHit hit;
-      if(P.pc.useShadows == 1)  // rgen:81-131
+      float visibility = 1.0f, lightDistance = 0.0f;
+      f3 L = mk3(1.0f, 0.0f, 0.0f);
+      bool want = false;
+      if(shaded)
       {
-        float visibility = 1.0f;
         const int random_index = (int)(rnd(prd.seed) * (float)P.pc.lightsCount);
         const float4 l0 = ((const float4*)&sc.lights[random_index])[0];
         const f3 lightDir = mk3(l0.x, l0.y, l0.z) - worldPos;
-        const float lightDistance = length3(lightDir);
-        const f3 L = normalize3(lightDir);
+        lightDistance = length3(lightDir);
+        L = normalize3(lightDir);
         if(dot3(L, worldNrm) < 0.0f)
           visibility = 0.0f;
         else
+          want = true;
+      }
+      if(anyLane(want))
+      {
+        hyTrace<WIDE, SHARE>(sc, want, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, shareLds, hit, tc);
+        if(want)
         {
           nShadow++;
-          traverse_any<false, WIDE>(sc, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
           if(hit.slot >= 0)
             visibility = 0.0f;
         }
+      }
+      if(shaded)
+      {
         visibility = glsl_max(visibility, 0.01f);
         color.w *= visibility;
       }
-      if(P.pc.useAO == 1)  // rgen:134-169
-      {
-        float ao = 0.0f;
-        f3 tangent, binormal;
+    }
+    if(P.pc.useAO == 1)  // rgen:134-169
+    {
+      float ao = 0.0f;
+      f3 tangent = mk3(0.0f), binormal = mk3(0.0f);
+      if(shaded)
         createCoordinateSystem(worldNrm, tangent, binormal);
-        const float weightAo = 1.0f / 4;
-        for(int i = 0; i < 4; i++)
+      const float weightAo = 1.0f / 4;
+      for(int i = 0; i < 4; i++)
+      {
+        f3 rayDir = mk3(1.0f, 0.0f, 0.0f);
+        if(shaded)
+          rayDir = normalize3(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
+        hyTrace<WIDE, SHARE>(sc, shaded, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, shareLds, hit, tc);
+        if(shaded)
         {
-          const f3 rayDir = normalize3(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
           nShadow++;
-          traverse_any<false, WIDE>(sc, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
           if(hit.slot >= 0)
             ao += weightAo;
         }
-        color.w *= (1.0f - ao);
       }
-      if(P.pc.useGI == 1)  // rgen:172-282
+      if(shaded)
+        color.w *= (1.0f - ao);
+    }
+    if(P.pc.useGI == 1)  // rgen:172-282
+    {
+      f3 curWeight = mk3(0.0f), hitValue = mk3(0.0f);
+      float hitDists = 0.0f;
+      if(shaded)
       {
-        f3 direction, curWeight;
+        f3 direction;
         const float ratio = metalness * (1.0f - roughness);
         if(ratio < 0.8f)
         {
@@ -375,25 +441,34 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
         prd.rayDirection = direction;
         prd.depth = 1;
         prd.weight = mk3(0.0f);
-        f3 hitValue = mk3(0.0f);
-        float hitDists = 0.0f;
-        for(; prd.depth < (uint32_t)P.pc.depth; prd.depth++)
+      }
+      bool active = shaded && prd.depth < (uint32_t)P.pc.depth;
+      while(anyLane(active))
+      {
+        const f3 rd = prd.rayDirection;
+        hyTrace<WIDE, SHARE>(sc, active, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, shareLds, hit, tc);
+        bool needShadow = false;
+        if(active)
         {
           nClosest++;
-          const f3 rd = prd.rayDirection;
-          traverse_any<false, WIDE>(sc, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
           if(hit.slot >= 0)
             closestHitShader(sc, P.pc, hit, rd, prd, st);
           else
             missShader(P.pc, prd);
-          bool shadowHit = false;
-          if(!prd.isSpecular && prd.depth != 100u)
+          needShadow = !prd.isSpecular && prd.depth != 100u;
+        }
+        bool shadowHit = false;
+        if(anyLane(needShadow))
+        {
+          hyTrace<WIDE, SHARE>(sc, needShadow, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, shareLds, hit, tc);
+          if(needShadow)
           {
             nShadow++;
-            traverse_any<false, WIDE>(sc, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, (int)threadIdx.x, HY_BLOCK,
-                                      hit, tc);
             shadowHit = hit.slot >= 0;
           }
+        }
+        if(active)
+        {
           if(!shadowHit)
           {
             const f3 q = prd.hitValue * curWeight;
@@ -402,7 +477,12 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
           if(prd.depth == 1u && !prd.isSpecular)  // rgen:253-264
             hitDists = shadowHit ? 0.5f * prd.lightDist : prd.lightDist;
           curWeight = curWeight * prd.weight;
+          prd.depth++;
+          active = prd.depth < (uint32_t)P.pc.depth;
         }
+      }
+      if(shaded)
+      {
         color.x = hitValue.x; color.y = hitValue.y; color.z = hitValue.z;
         if(H.nrdRadHitD)
         {  // rgen:273-281: REBLUR front end, hitDistParams (3, 1, 20, -25), rgba16f store
@@ -423,6 +503,9 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
         }
       }
     }
+  }
+  if(inImage)
+  {
     // accumulateFrames, rgen:36-48 (all four channels)
     if(P.pc.frame > 0)
     {
@@ -434,7 +517,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_hybrid(const HybridParams H)
     else
       H.accum[p] = color;
   }
-  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (HY_BLOCK / 64)];
+  __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * ((SHARE ? 64 : HY_BLOCK) / 64)];
   const unsigned vals[6] = {nClosest, nShadow, st.hits, st.diffuse, st.taps, nPixels};
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 6, red);
 }
@@ -497,12 +580,17 @@ hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const fl
   H.color = (float4*)color; H.position = (float4*)position; H.normal = (float4*)normal; H.rough = (float2*)rough; H.accum = (float4*)accum;
   for(int k = 0; k < 4; k++) H.clearColor[k] = 0.0f;
   H.lightsCount = P.pc.lightsCount;
-  const unsigned blocks = (P.tileCount * 64u + HY_BLOCK - 1) / HY_BLOCK;
-  const size_t lds = (size_t)P.sc.stackCap * HY_BLOCK * sizeof(int);
-  if(P.sc.layout == 1u)
-    hipLaunchKernelGGL(k_hybrid<true>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  // with the wide layout and work sharing enabled (the defaults) one wave per workgroup walks its 64 pixels' rays together
+  const bool share = P.sc.layout == 1u && P.sc.shareMinIdle != 0u && P.sc.triThreshold != 0u;
+  const unsigned block = share ? 64u : (unsigned)HY_BLOCK;
+  const unsigned blocks = (P.tileCount * 64u + block - 1) / block;
+  const size_t lds = (size_t)P.sc.stackCap * block * sizeof(int);
+  if(share)
+    hipLaunchKernelGGL((k_hybrid<true, true>), dim3(blocks), dim3(block), lds, stream, H);
+  else if(P.sc.layout == 1u)
+    hipLaunchKernelGGL((k_hybrid<true, false>), dim3(blocks), dim3(block), lds, stream, H);
   else
-    hipLaunchKernelGGL(k_hybrid<false>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+    hipLaunchKernelGGL((k_hybrid<false, false>), dim3(blocks), dim3(block), lds, stream, H);
   return hipGetLastError();
 }
 
