@@ -152,7 +152,7 @@ def test_gpu_hybrid_textured_atrium_and_toggles():
     pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
     shared = r.hybrid_trace(pc, cam, W, H, g, seed=11).cpu().numpy()
     r.close()
-    for opts in ({abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_BVH_LAYOUT: 0}):
+    for opts in ({abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_BVH_LAYOUT: 0}, {abi.VKRT_OPT_MODE: 0}):  # MODE 0: the whole rgen in one kernel (no streams)
         r2 = Renderer(flat, device=0, build="sah", options=opts)
         alone = r2.hybrid_trace(pc, cam, W, H, g, seed=11).cpu().numpy()
         r2.close()

@@ -166,3 +166,36 @@ VKRT_DEV f3 samplingNDF_GGXTR(uint32_t& seed, float alpha2)
   vk_sincos(phi, &sinPhi, &cosPhi);
   return mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
+
+// rg16f / rgba16f / r16f stores of the hybrid mode: float -> half (RNE) -> float, integer-exact (same routine as the oracle)
+VKRT_DEV float quantizeHalf(float f)
+{
+  const uint32_t x = __float_as_uint(f);
+  const uint32_t sign = x & 0x80000000u;
+  uint32_t ax = x & 0x7fffffffu;
+  if(ax >= 0x7f800000u)
+    return f;
+  if(ax < 0x38800000u)
+  {
+    const uint32_t e = ax >> 23;
+    if(e < 101u)
+      ax = 0u;
+    else
+    {
+      const uint32_t mant = (ax & 0x7fffffu) | 0x800000u;
+      const uint32_t shift = 126u - e;
+      uint32_t q = mant >> shift;
+      const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+      if(rem > half || (rem == half && (q & 1u))) q++;
+      ax = __float_as_uint((float)q * 5.9604644775390625e-8f);
+    }
+  }
+  else
+  {
+    const uint32_t rem = ax & 0x1fffu;
+    ax &= ~0x1fffu;
+    if(rem > 0x1000u || (rem == 0x1000u && (ax & 0x2000u))) ax += 0x2000u;
+    if(ax >= 0x47800000u) ax = 0x7f800000u;
+  }
+  return __uint_as_float(sign | ax);
+}

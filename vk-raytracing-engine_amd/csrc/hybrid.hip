@@ -21,39 +21,6 @@
 
 #define HY_BLOCK 256
 
-// rg16f store of (roughness, metalness): float -> half (RNE) -> float, integer-exact (same routine as the oracle)
-VKRT_DEV float quantizeHalf(float f)
-{
-  const uint32_t x = __float_as_uint(f);
-  const uint32_t sign = x & 0x80000000u;
-  uint32_t ax = x & 0x7fffffffu;
-  if(ax >= 0x7f800000u)
-    return f;
-  if(ax < 0x38800000u)
-  {
-    const uint32_t e = ax >> 23;
-    if(e < 101u)
-      ax = 0u;
-    else
-    {
-      const uint32_t mant = (ax & 0x7fffffu) | 0x800000u;
-      const uint32_t shift = 126u - e;
-      uint32_t q = mant >> shift;
-      const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1u);
-      if(rem > half || (rem == half && (q & 1u))) q++;
-      ax = __float_as_uint((float)q * 5.9604644775390625e-8f);
-    }
-  }
-  else
-  {
-    const uint32_t rem = ax & 0x1fffu;
-    ax &= ~0x1fffu;
-    if(rem > 0x1000u || (rem == 0x1000u && (ax & 0x2000u))) ax += 0x2000u;
-    if(ax >= 0x47800000u) ax = 0x7f800000u;
-  }
-  return __uint_as_float(sign | ax);
-}
-
 struct HybridParams
 {
   TraceParams T;      // scene, pc, camera, launch geometry (image pointer unused)
@@ -69,6 +36,7 @@ struct HybridParams
   float* nrdViewZ;       // eInViewZ     r16f values
   float4* nrdRadHitD;    // eInRadHitD   rgba16f values
   float viewMatrix[16];  // pcRaster.viewMatrix (column-major), for viewZ
+  uint2* giLater;        // k_hybrid: non-NULL = GI runs afterwards on the wavefront streams; (seed, visibility bits) per pixel go here
 };
 
 // ---- NRD / REBLUR front-end packing, gltf.glsl:156-273 (same operation order as the oracle) -----------------------------
@@ -411,7 +379,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
       if(shaded)
         color.w *= (1.0f - ao);
     }
-    if(P.pc.useGI == 1)  // rgen:172-282
+    if(P.pc.useGI == 1 && !H.giLater)  // rgen:172-282
     {
       f3 curWeight = mk3(0.0f), hitValue = mk3(0.0f);
       float hitDists = 0.0f;
@@ -504,7 +472,9 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
       }
     }
   }
-  if(inImage)
+  if(inImage && H.giLater && P.pc.useGI == 1)
+    H.giLater[p] = make_uint2(prd.seed, __float_as_uint(color.w));  // the GI kernels continue from here and write the pixel
+  else if(inImage)
   {
     // accumulateFrames, rgen:36-48 (all four channels)
     if(P.pc.frame > 0)
@@ -552,6 +522,7 @@ hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], 
 {
   HybridParams H;
   H.T = P;
+  H.giLater = nullptr;
   H.nrdNormRough = nrd ? (float4*)nrd->normRough : nullptr;
   H.nrdViewZ = nrd ? nrd->viewZ : nullptr;
   H.nrdRadHitD = nrd ? (float4*)nrd->radHitD : nullptr;
@@ -569,10 +540,11 @@ hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], 
 }
 
 hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const float* position, const float* normal, const float* rough, float* accum,
-                              const NrdPlanes* nrd, hipStream_t stream)
+                              const NrdPlanes* nrd, uint2* giLater, hipStream_t stream)
 {
   HybridParams H;
   H.T = P;
+  H.giLater = giLater;
   H.nrdNormRough = nullptr;
   H.nrdViewZ = nrd ? nrd->viewZ : nullptr;
   H.nrdRadHitD = nrd ? (float4*)nrd->radHitD : nullptr;

@@ -47,7 +47,24 @@ struct NrdPlanes  // optional NRD front-end attachments (include/vkrt.h vkrt_nrd
 };
 hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], int lightsCount, float* color, float* position, float* normal,
                                float* rough, const NrdPlanes* nrd, hipStream_t stream);
+// giLater: non-NULL = the GI part follows on the wavefront streams (vkrt_launch_hybrid_gi): the kernel does shadows + AO only and
+// leaves (seed, visibility) per pixel there instead of writing the accumulation image
 hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const float* position, const float* normal, const float* rough, float* accum,
-                              const NrdPlanes* nrd, hipStream_t stream);
+                              const NrdPlanes* nrd, uint2* giLater, hipStream_t stream);
+// GI of the hybrid mode on the path tracer's wavefront streams (wavefront.hip): k_hybrid (direct part, tmp = per-pixel seed and
+// visibility) -> k_hy_gi_init (first GI ray of every shaded pixel) -> pc.depth rounds of traverse / shade -> accumulation image.
+struct HybridGi
+{
+  const float4* color;     // G-buffer planes (read)
+  const float4* position;
+  const float4* normal;
+  const float2* rough;
+  float4* accum;           // rgba32f accumulation image (read-modify-write)
+  float4* nrdRadHitD;      // optional NRD plane (NULL = not requested)
+  const float* nrdViewZ;
+};
+hipError_t vkrt_launch_hybrid_gi(const TraceParams& P, const WfBuffers& B, const HybridGi& G, unsigned travBlock, hipStream_t stream);
+// the scratch plane k_hybrid leaves the per-pixel (seed, visibility) in for vkrt_launch_hybrid_gi
+uint2* vkrt_wf_hybrid_tmp(const WfBuffers& B);
 hipError_t vkrt_launch_post(int rtMode, int viewAccumulated, int useGI, unsigned n, const float* mainImg, const float* rtImg, float* out,
                             hipStream_t stream);

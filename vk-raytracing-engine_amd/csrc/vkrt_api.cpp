@@ -941,7 +941,22 @@ int hybridImpl(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* c
   {
     np.viewZ = nrd->viewZ; np.radHitD = nrd->diffRadianceHitDist;
   }
-  HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, stream));
+  // The GI paths (raytraceHybrid.rgen:172-282) run on the path tracer's wavefront streams when the scene was built for them:
+  // k_hybrid does the shadow and AO rays and leaves the per-pixel state for k_hy_gi_init (wavefront.hip).  The megakernel mode
+  // keeps the whole rgen in k_hybrid.
+  const bool giOnStreams = s->wavefront && pc->useGI == 1 && P.fullW <= 65535u && P.localRows <= 65535u;
+  if(giOnStreams)
+  {
+    if((rc = ensureWorkingSet(s, P.tileCount * 64u, stream)) != VKRT_OK)
+      return rc;
+    P.tileFirst = 0;
+    HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, vkrt_wf_hybrid_tmp(s->wf), stream));
+    HybridGi G{(const float4*)g->color, (const float4*)g->position, (const float4*)g->normal, (const float2*)g->roughMetal, (float4*)accum,
+               nrd ? (float4*)nrd->diffRadianceHitDist : nullptr, nrd ? nrd->viewZ : nullptr};
+    HIP_TRY(vkrt_launch_hybrid_gi(P, s->wf, G, (unsigned)s->opt[VKRT_OPT_WF_TRAV_BLOCK], stream));
+  }
+  else
+    HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, nullptr, stream));
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->timed = true;
   s->wfTimed = false;

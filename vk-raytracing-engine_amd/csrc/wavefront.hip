@@ -52,7 +52,7 @@
 // ray; type 1 "S": a shadow ray, and the segment it belongs to is the last of its sample; type 2 "P" (pair): the shadow ray
 // of segment k and the closest-hit ray of segment k + 1, both from the hit point of segment k.
 //   plane 0  R0  ray origin.xyz, tmax of the first ray (C: 10000; S, P: lightDist - 0.1)      written by the producer
-//   plane 1  R1  direction of the first ray (C: closest-hit ray; S, P: shadow ray), -
+//   plane 1  R1  direction of the first ray (C: closest-hit ray; S, P: shadow ray), S, P: lightDist (read by the hybrid mode only)
 //   plane 2  R2  P: direction of the closest-hit ray of the next segment (prd.rayDirection), -
 //   plane 3  H0  written by k_wf_traverse.  C: t, u, v, instance id (-1 = miss).  S: .w = 0 occluded / -1 not.
 //                P: .x = 1 occluded / 0 not (stored by the shadow lane), .y .z .w = u, v, instance id of the closest-hit ray
@@ -119,7 +119,7 @@ VKRT_DEV void storeClosest(const WfBuffers& B, int parity, unsigned i, const Lan
 VKRT_DEV void storeShadow(const WfBuffers& B, int parity, int type, unsigned i, const LaneState& L, f3 contrib, f3 nextWeight)
 {
   plane(B, parity, type, WF_R0)[i] = make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, L.prd.lightDist - 0.1f);
-  plane(B, parity, type, WF_R1)[i] = make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, 0.0f);
+  plane(B, parity, type, WF_R1)[i] = make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, L.prd.lightDist);
   if(type == WF_P)
     plane(B, parity, type, WF_R2)[i] = make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f);
   storeState(B, parity, type, i, L, nextWeight);
@@ -294,14 +294,74 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
   }
 }
 
+// ---- hybrid mode: the GI path of raytraceHybrid.rgen:172-282 on the same streams ----------------------------------------------
+// A pixel's GI path is one sample that starts at depth 1 from the G-buffer position; its record is the path tracer's, with the
+// S2 plane (unused: there is no sum over samples) carrying hitDists (.x, rgen:253-264) and the visibility term of the direct
+// part (.y, the alpha of the accumulation image).  HYBRID instantiations of the shade functions end a sample with hybridFinish
+// instead of storePixel and keep hitDists; everything else -- rays, shaders, compaction -- is shared with the path tracer.
+// raytraceHybrid.rgen:266-282 + 36-48: the pixel's GI radiance is complete
+VKRT_DEV void hybridFinish(const TraceParams& P, const HybridGi& G, uint32_t px, uint32_t lrow, bool shaded, f3 hitValue, float hitDists, float alpha)
+{
+  const size_t p = (size_t)lrow * P.fullW + px;
+  float4 color = make_float4(0.0f, 0.0f, 0.0f, alpha);
+  if(shaded)
+  {
+    color.x = hitValue.x; color.y = hitValue.y; color.z = hitValue.z;
+    if(G.nrdRadHitD)
+    {  // REBLUR front end, hitDistParams (3, 1, 20, -25), rgba16f store (same operation order as k_hybrid)
+      const float roughness = G.rough[p].x;
+      const float viewZ = G.nrdViewZ[p];
+      const float t = glsl_clamp(exp2f(-25.0f * roughness * roughness), 0.0f, 1.0f);
+      const float f = (3.0f + fabsf(viewZ) * 1.0f) * (1.0f * (1.0f - t) + 20.0f * t);
+      float normHitDist = glsl_clamp(hitDists / f, 0.0f, 1.0f);
+      f3 rad = hitValue;
+      const bool bad = isnan(rad.x) || isnan(rad.y) || isnan(rad.z) || isinf(rad.x) || isinf(rad.y) || isinf(rad.z);
+      rad = bad ? mk3(0.0f) : mk3(glsl_clamp(rad.x, 0.0f, 65504.0f), glsl_clamp(rad.y, 0.0f, 65504.0f), glsl_clamp(rad.z, 0.0f, 65504.0f));
+      normHitDist = (isnan(normHitDist) || isinf(normHitDist)) ? 0.0f : glsl_clamp(normHitDist, 0.0f, 1.0f);
+      if(normHitDist != 0.0f)
+        normHitDist = glsl_max(normHitDist, 1e-7f);
+      const float Y = (rad.x * 0.25f + rad.y * 0.5f) + rad.z * 0.25f;
+      const float Co = (rad.x * 0.5f + rad.y * 0.0f) + rad.z * -0.5f;
+      const float Cg = (rad.x * -0.25f + rad.y * 0.5f) + rad.z * -0.25f;
+      G.nrdRadHitD[p] = make_float4(quantizeHalf(Y), quantizeHalf(Co), quantizeHalf(Cg), quantizeHalf(normHitDist));
+    }
+  }
+  if(P.pc.frame > 0)  // accumulateFrames, rgen:36-48 (all four channels)
+  {
+    const float a = 1.0f / (float)(P.pc.frame + 1);
+    const float4 old = G.accum[p];
+    G.accum[p] = make_float4(old.x * (1.0f - a) + color.x * a, old.y * (1.0f - a) + color.y * a, old.z * (1.0f - a) + color.z * a,
+                             old.w * (1.0f - a) + color.w * a);
+  }
+  else
+    G.accum[p] = color;
+}
+// rgen:240-266 for one finished segment of the GI path; false = the path (and the pixel) is complete
+VKRT_DEV bool advanceSegmentHybrid(const TraceParams& P, const HybridGi& G, LaneState& L, bool shadowHit, f3 contrib, f3 nextWeight, float lightDist)
+{
+  L.stage = 0;
+  if(!shadowHit)
+    L.hitValue = L.hitValue + contrib;
+  if(L.prd.depth == 1u && !L.prd.isSpecular)  // rgen:253-264 (only segments that traced a shadow ray get here with depth 1)
+    L.hitValues.x = shadowHit ? 0.5f * lightDist : lightDist;
+  L.curWeight = nextWeight;
+  L.prd.depth++;
+  if(!(L.prd.depth < (uint32_t)P.pc.depth))
+  {
+    hybridFinish(P, G, L.px, L.lrow, true, L.hitValue, L.hitValues.x, L.hitValues.y);
+    return false;
+  }
+  return true;
+}
+
 // ---- shade, results of streams C and P: [finish segment k,] rchit / rmiss of the traced closest-hit ray, then the next ray(s) ----
 // (Regrouping the 256 results of a workgroup by lobe through LDS between the hit shader's front half and its diffuse / specular
 // tail -- closestHitFront / closestHitLobe / closestHitTail in shade.h -- so that a wave runs one branch only was built and
 // measured in round 2: bit-identical images, ~30 % fewer VALU instructions, no change in kernel time (5.94 vs 5.91 ms per
 // 4-spp frame): the stage is bound by its stream traffic to HBM and the latency of its gathers, not by issue.  Removed again;
 // profiles/r02_experiments.md #52.)
-template <bool PAIR>
-VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
+template <bool PAIR, bool HYBRID>
+VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const HybridGi& G, const int par, const unsigned count, const unsigned block)
 {
   const int type = PAIR ? WF_P : WF_C;
   const unsigned lane = lane_id();
@@ -327,7 +387,10 @@ VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const int 
       // the segment is never the last of its sample (emission rule below), so advanceSegment only accumulates and steps depth
       const float4 s3 = plane(B, par, WF_P, WF_S3)[qi];
       const bool shadowHit = __float_as_int(h.x) != 0;
-      (void)advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
+      if(HYBRID)
+        (void)advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? plane(B, par, WF_P, WF_R1)[qi].w : 0.0f);
+      else
+        (void)advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
     }
     RayHit hit;
     hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.slot = __float_as_int(h.w);  // instance id of the hit (>= 0) or -1; t is not used by the shaders
@@ -339,6 +402,8 @@ VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const int 
     segmentTerms(L, contrib, nextWeight);
     if(!L.prd.isSpecular && L.prd.depth != 100u)  // rgen:79: a shadow ray decides whether this segment contributes
       to = (L.prd.depth + 1u < (uint32_t)P.pc.depth) ? WF_P : WF_S;  // not the last segment: the next closest-hit ray rides along
+    else if(HYBRID)
+      to = advanceSegmentHybrid(P, G, L, false, contrib, nextWeight, 0.0f) ? WF_C : -1;
     else
       to = advanceSegment(P, L, false, contrib, nextWeight) ? WF_C : -1;
   }
@@ -356,7 +421,8 @@ VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const int 
 }
 
 // ---- shade, results of stream S: the last segment of a sample (rgen:99-120), next sample or pixel store (light; many waves) ----
-VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const int par, const unsigned count, const unsigned block)
+template <bool HYBRID>
+VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const HybridGi& G, const int par, const unsigned count, const unsigned block)
 {
   const unsigned lane = lane_id();
   const unsigned qi = block * WF_BLOCK + threadIdx.x;
@@ -370,7 +436,10 @@ VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const i
     L.prd.rayOrigin = mk3(0.0f);     // the sample ends here: startSample sets the next ray, or the pixel is stored
     L.prd.rayDirection = mk3(0.0f);
     const bool shadowHit = __float_as_int(h.w) >= 0;
-    toClosest = advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
+    if(HYBRID)
+      toClosest = advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? plane(B, par, WF_S, WF_R1)[qi].w : 0.0f);
+    else
+      toClosest = advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
   }
   const unsigned slot = claimSlots(B, par ^ 1, toClosest ? WF_C : -1, lane, wsum);
   if(toClosest)
@@ -379,18 +448,100 @@ VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const i
 
 // One launch shades the three result streams of a round: the heavy workgroups (C, then P) are dispatched first, the light
 // shadow-result workgroups fill in behind them.
-__global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
+template <bool HYBRID>
+VKRT_DEV void shadeRound(const TraceParams& P, const WfBuffers& B, const HybridGi& G, const int round)
 {
   const int par = round & 1;
   const unsigned cC = *countOf(B, par, WF_C), cS = *countOf(B, par, WF_S), cP = *countOf(B, par, WF_P);
   const unsigned nC = (cC + WF_BLOCK - 1) / WF_BLOCK, nP = (cP + WF_BLOCK - 1) / WF_BLOCK, nS = (cS + WF_BLOCK - 1) / WF_BLOCK;
   unsigned blk = blockIdx.x;
   if(blk < nC)
-    shadeHitBlock<false>(P, B, par, cC, blk);
+    shadeHitBlock<false, HYBRID>(P, B, G, par, cC, blk);
   else if((blk -= nC) < nP)
-    shadeHitBlock<true>(P, B, par, cP, blk);
+    shadeHitBlock<true, HYBRID>(P, B, G, par, cP, blk);
   else if((blk -= nP) < nS)
-    shadeShadowBlock(P, B, par, cS, blk);
+    shadeShadowBlock<HYBRID>(P, B, G, par, cS, blk);
+}
+__global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
+{
+  const HybridGi none{};
+  shadeRound<false>(P, B, none, round);
+}
+__global__ __launch_bounds__(WF_BLOCK) void k_wf_shade_hybrid(const TraceParams P, const WfBuffers B, const HybridGi G, const int round)
+{
+  shadeRound<true>(P, B, G, round);
+}
+
+// First ray of the GI path of every shaded pixel (raytraceHybrid.rgen:172-204), or the pixel's final value when there is no path
+// to trace.  tmp: (seed after the direct part, visibility) per pixel, left by k_hybrid.
+__global__ __launch_bounds__(WF_BLOCK) void k_hy_gi_init(const TraceParams P, const WfBuffers B, const HybridGi G, const uint2* tmp)
+{
+  const unsigned lane = lane_id();
+  const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;  // tile-major work index
+  bool alive = false;
+  LaneState L;
+  if(w < P.tileCount * 64u)
+  {
+    const unsigned tile = P.tileFirst + (w >> 6), inTile = w & 63u;
+    const uint32_t x = (tile % P.tilesX) * 8u + (inTile & 7u);
+    const uint32_t lrow = (tile / P.tilesX) * 8u + (inTile >> 3);
+    if(x < P.fullW && lrow < P.localRows && globalRow(P, lrow) < P.fullH)
+    {
+      const size_t p = (size_t)lrow * P.fullW + x;
+      const float4 pixelImg = G.color[p], pixelPos = G.position[p], pixelNorm = G.normal[p];
+      const float2 rm = G.rough[p];
+      const uint2 t = tmp[p];
+      const f3 worldPos = mk3(pixelPos.x, pixelPos.y, pixelPos.z), worldNrm = mk3(pixelNorm.x, pixelNorm.y, pixelNorm.z);
+      const bool shaded = !(worldPos.x == 0.0f && worldPos.y == 0.0f && worldPos.z == 0.0f && worldNrm.x == 0.0f && worldNrm.y == 0.0f &&
+                            worldNrm.z == 0.0f);  // rgen:67
+      const float alpha = __uint_as_float(t.y);
+      if(!shaded)
+        hybridFinish(P, G, x, lrow, false, mk3(0.0f), 0.0f, alpha);
+      else
+      {
+        L.px = x; L.lrow = lrow;
+        L.prd.seed = t.x;
+        L.prd.lightDist = 0.0f; L.prd.shadowRayDir = mk3(0.0f);
+        const float roughness = rm.x, metalness = rm.y;
+        const float ratio = metalness * (1.0f - roughness);
+        f3 direction;
+        if(ratio < 0.8f)
+        {
+          L.prd.isSpecular = false;
+          f3 tangent, binormal;
+          createCoordinateSystem(worldNrm, tangent, binormal);
+          direction = normalize3(samplingHemisphere(L.prd.seed, tangent, binormal, worldNrm));
+          L.curWeight = mk3(pixelImg.w, pixelPos.w, pixelNorm.w);  // albedo
+        }
+        else
+        {
+          L.prd.isSpecular = true;
+          float cam[4];
+          mat4MulVec4(P.viewInverse, 0.0f, 0.0f, 0.0f, 1.0f, cam);
+          const f3 V = normalize3(mk3(cam[0], cam[1], cam[2]) - worldPos);
+          direction = normalize3(glsl_reflect(-V, worldNrm));
+          L.curWeight = mk3(1.0f);
+        }
+        L.prd.hitValue = mk3(0.0f);
+        L.prd.rayOrigin = worldPos;
+        L.prd.rayDirection = direction;
+        L.prd.depth = 1;
+        L.prd.weight = mk3(0.0f);
+        L.hitValue = mk3(0.0f);
+        L.hitValues = mk3(0.0f, alpha, 0.0f);  // .x hitDists, .y visibility
+        L.smpl = 0;
+        L.stage = 0;
+        if(L.prd.depth < (uint32_t)P.pc.depth)
+          alive = true;
+        else
+          hybridFinish(P, G, x, lrow, true, mk3(0.0f), 0.0f, alpha);
+      }
+    }
+  }
+  __shared__ unsigned wsum[WF_TYPES * (WF_BLOCK / 64 + 1)];
+  const unsigned slot = claimSlots(B, 0, alive ? WF_C : -1, lane, wsum);
+  if(alive)
+    storeClosest(B, 0, slot, L);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -494,6 +645,49 @@ static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsig
       timing->used++;
     }
     hipLaunchKernelGGL(k_wf_shade, dim3(blocks + 3), bb, 0, stream, P, B, r);
+  }
+  return hipGetLastError();
+}
+
+// ---- hybrid GI -------------------------------------------------------------------------------------------------------
+uint2* vkrt_wf_hybrid_tmp(const WfBuffers& B)
+{
+  // the streams of parity 1 are first written by the shade step of round 0: until then their first plane is free
+  return (uint2*)(B.planes + (size_t)(1 * WF_TYPES + 0) * WF_PLANES * B.capacity);
+}
+
+hipError_t vkrt_launch_hybrid_gi(const TraceParams& P, const WfBuffers& B, const HybridGi& G, unsigned travBlock, hipStream_t stream)
+{
+  const unsigned work = P.tileCount * 64u;
+  hipError_t e = hipMemsetAsync(B.ctrl, 0, 64, stream);
+  if(e != hipSuccess)
+    return e;
+  const unsigned blocks = (work + WF_BLOCK - 1) / WF_BLOCK;
+  hipLaunchKernelGGL(k_hy_gi_init, dim3(blocks), dim3(WF_BLOCK), 0, stream, P, B, G, (const uint2*)vkrt_wf_hybrid_tmp(B));
+  // the GI path is one sample that starts at depth 1: at most pc.depth - 1 segments, i.e. pc.depth rounds of the paired pipeline
+  const int rounds = P.pc.depth;
+  const bool wide = P.sc.layout == 1u;
+  const unsigned tbs = (travBlock == 256u || travBlock == 128u) ? travBlock : 64u;
+  const dim3 tg(2 * ((work + tbs - 1) / tbs) + 4), tb(tbs);
+  const size_t tlds = (size_t)P.sc.stackCap * tbs * sizeof(int);
+  for(int r = 0; r < rounds; r++)
+  {
+    if(tbs == 64u)
+    {
+      if(wide) hipLaunchKernelGGL((k_wf_traverse<false, true, 64>), tg, tb, tlds, stream, P, B, r);
+      else hipLaunchKernelGGL((k_wf_traverse<false, false, 64>), tg, tb, tlds, stream, P, B, r);
+    }
+    else if(tbs == 128u)
+    {
+      if(wide) hipLaunchKernelGGL((k_wf_traverse<false, true, 128>), tg, tb, tlds, stream, P, B, r);
+      else hipLaunchKernelGGL((k_wf_traverse<false, false, 128>), tg, tb, tlds, stream, P, B, r);
+    }
+    else
+    {
+      if(wide) hipLaunchKernelGGL((k_wf_traverse<false, true, 256>), tg, tb, tlds, stream, P, B, r);
+      else hipLaunchKernelGGL((k_wf_traverse<false, false, 256>), tg, tb, tlds, stream, P, B, r);
+    }
+    hipLaunchKernelGGL(k_wf_shade_hybrid, dim3(blocks + 3), dim3(WF_BLOCK), 0, stream, P, B, G, r);
   }
   return hipGetLastError();
 }
