@@ -159,6 +159,40 @@ def test_gpu_hybrid_textured_atrium_and_toggles():
         assert np.array_equal(shared.view(np.uint32), alone.view(np.uint32)), opts
 
 
+@pytest.mark.gpu
+def test_gpu_hybrid_sharded_equals_whole_frame(small_scene):
+    """The hybrid passes under image-strip sharding (vkrt_shard): each shard's G-buffer, accumulated plane (two progressive frames,
+    GI paths on the wavefront streams) and NRD planes are the rows of the unsharded result, bit for bit."""
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat, camkw = small_scene
+    W, H = 200, 150  # not a multiple of the 8x8 tiles or of the 16-row strips
+    cam = default_camera(W, H, **camkw)
+    vm = _view_matrix(camkw)
+    L = len(flat.lights)
+    r = Renderer(flat, device=0)
+
+    def frames(shard):
+        g = r.gbuffer_raycast(cam, W, H, lights_count=L, view_matrix=vm, shard=shard)
+        acc = None
+        for f in range(2):
+            pc = make_push_constants(samples=1, depth=5, frame=f, lights_count=L)
+            pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+            acc = r.hybrid_trace(pc, cam, W, H, g, seed=20 + f, accum=acc, shard=shard)
+        return {**{k: v.cpu().numpy() for k, v in g.items()}, "accum": acc.cpu().numpy()}
+
+    whole = frames(None)
+    for count, index in ((3, 0), (3, 2), (4, 1)):
+        part = frames(abi.Shard(W, H, 16, count, index))
+        rows = [y for y in range(H) if (y // 16) % count == index]
+        for k, v in part.items():
+            assert v.shape[0] == len(rows), k
+            assert np.array_equal(v.view(np.uint32), whole[k][rows].view(np.uint32)), (count, index, k)
+    r.close()
+
+
 # ---- NRD / REBLUR front-end planes (SURVEY 8f row 4; gltf.glsl:156-273) -------------------------------------------------
 @pytest.fixture(scope="module")
 def small_scene():
