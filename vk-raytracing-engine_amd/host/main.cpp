@@ -4,6 +4,7 @@
 // writes the rgba32f image (PFM) and a gamma-2.2 preview (PPM, post.frag:39).
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -24,6 +25,8 @@ using namespace vkrt_host;
 // find each other through the RCCL id file.  Returns the worst child exit code.
 static int spawnRanks(int ranks, int argc, char** argv)
 {
+  // RCCL between processes needs dmabuf IPC on hosts whose driver has no legacy IPC (hipIpcGetMemHandle: invalid argument otherwise)
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
   char idFile[64];
   snprintf(idFile, sizeof idFile, "/tmp/vkrt_rccl_id_%d", (int)getpid());
   unlink(idFile);
