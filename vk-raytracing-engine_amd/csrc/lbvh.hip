@@ -424,6 +424,103 @@ struct TopBuilder
       b[3 + q] = std::max(b[3 + q], o[3 + q]);
     }
   }
+  // node over [a, b) split at `split` (entries already partitioned): box, count, children
+  int finishNode(size_t a, size_t b, size_t split, TopNode node)
+  {
+    float bx[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for(size_t k = a; k < b; k++)
+    {
+      grow(bx, e[k].box);
+      cnt += e[k].count;
+    }
+    for(int q = 0; q < 6; q++) node.box[q] = bx[q];
+    node.count = cnt;
+    const size_t slot = out.size();
+    out.push_back(node);
+    const int l = build(a, split), r = build(split, b);
+    out[slot].left = l;
+    out[slot].right = r;
+    return node.id;
+  }
+  // large ranges: 32 bins per axis over the centroid bounds (O(n) per node instead of three sorts)
+  int buildBinned(size_t a, size_t b, TopNode node)
+  {
+    const int kBins = 32;
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for(size_t k = a; k < b; k++)
+      for(int q = 0; q < 3; q++)
+      {
+        const float c = e[k].box[q] + e[k].box[3 + q];
+        clo[q] = std::min(clo[q], c);
+        chi[q] = std::max(chi[q], c);
+      }
+    float best = INFINITY;
+    int bestAxis = -1, bestBin = 0;
+    for(int axis = 0; axis < 3; axis++)
+    {
+      const float ext = chi[axis] - clo[axis];
+      if(!(ext > 0.0f))
+        continue;
+      float bb[kBins][6];
+      int bc[kBins];
+      for(int k = 0; k < kBins; k++)
+      {
+        for(int q = 0; q < 3; q++) { bb[k][q] = INFINITY; bb[k][3 + q] = -INFINITY; }
+        bc[k] = 0;
+      }
+      const float scale = (float)kBins / ext;
+      for(size_t k = a; k < b; k++)
+      {
+        int bin = (int)(((e[k].box[axis] + e[k].box[3 + axis]) - clo[axis]) * scale);
+        bin = std::min(std::max(bin, 0), kBins - 1);
+        grow(bb[bin], e[k].box);
+        bc[bin] += e[k].count;
+      }
+      float ra[kBins];
+      int rc[kBins];
+      float acc[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int cnt = 0;
+      for(int k = kBins - 1; k > 0; k--)
+      {
+        if(bc[k]) grow(acc, bb[k]);
+        cnt += bc[k];
+        ra[k] = cnt ? area(acc) : 0.0f;
+        rc[k] = cnt;
+      }
+      float left[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int lc = 0;
+      for(int k = 1; k < kBins; k++)
+      {
+        if(bc[k - 1]) grow(left, bb[k - 1]);
+        lc += bc[k - 1];
+        if(lc == 0 || rc[k] == 0)
+          continue;
+        const float c = area(left) * (float)lc + ra[k] * (float)rc[k];
+        if(c < best)
+        {
+          best = c; bestAxis = axis; bestBin = k;
+        }
+      }
+    }
+    size_t split;
+    if(bestAxis < 0)
+      split = a + (b - a) / 2;  // all centroids coincide: any split will do
+    else
+    {
+      const float scale = (float)kBins / (chi[bestAxis] - clo[bestAxis]), lo = clo[bestAxis];
+      const int axis = bestAxis, cut = bestBin;
+      auto mid = std::stable_partition(e.begin() + a, e.begin() + b, [=](const TopEntry& x) {
+        int bin = (int)(((x.box[axis] + x.box[3 + axis]) - lo) * scale);
+        bin = std::min(std::max(bin, 0), kBins - 1);
+        return bin < cut;
+      });
+      split = (size_t)(mid - e.begin());
+      if(split == a || split == b)
+        split = a + (b - a) / 2;
+    }
+    return finishNode(a, b, split, node);
+  }
   int build(size_t a, size_t b)
   {
     if(b - a == 1)
@@ -431,6 +528,8 @@ struct TopBuilder
     const size_t n = b - a;
     TopNode node;
     node.id = ids[nextId++];
+    if(n > 1024)
+      return buildBinned(a, b, node);
     float best = INFINITY;
     int bestAxis = 0;
     size_t bestSplit = 1;
@@ -469,21 +568,7 @@ struct TopBuilder
         const float cx = x.box[bestAxis] + x.box[3 + bestAxis], cy = y.box[bestAxis] + y.box[3 + bestAxis];
         return cx < cy || (cx == cy && x.ref < y.ref);
       });
-    float bx[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    int cnt = 0;
-    for(size_t k = a; k < b; k++)
-    {
-      grow(bx, e[k].box);
-      cnt += e[k].count;
-    }
-    for(int q = 0; q < 6; q++) node.box[q] = bx[q];
-    node.count = cnt;
-    const size_t slot = out.size();
-    out.push_back(node);
-    const int l = build(a, a + bestSplit), r = build(a + bestSplit, b);
-    out[slot].left = l;
-    out[slot].right = r;
-    return node.id;
+    return finishNode(a, b, a + bestSplit, node);
   }
 };
 
@@ -637,6 +722,7 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
   if(topSah && T > 4096u)
   {
     // re-build the levels above subtrees of <= K triangles with a full-sweep SAH over those subtrees (see k_top_select)
+    // ~2 k subtrees whatever the scene size (16 k of them: twice the build time at 2 M triangles for the same ray rate, #71)
     unsigned K = std::max(16u, T / 2048u);
     if(const char* e = getenv("VKRT_TOP_SAH_LEAF"))  // test hook: triangles per frontier subtree
       K = (unsigned)std::max(8, atoi(e));
