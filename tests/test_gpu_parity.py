@@ -219,6 +219,11 @@ def test_error_paths(cornell_flat):
         r.pathtrace(make_push_constants(lights_count=5), cam, 32, 32)  # more lights than uploaded
     with pytest.raises(VkrtError):
         r.pathtrace(make_push_constants(lights_count=1), cam, 32, 32, shard=abi.Shard(32, 32, 0, 4, 1))
+    # vkrt_accel_build: exactly one builder; 0 = the default (device build, VKRT_BUILD_PLOC_GPU)
+    for flags in (abi.VKRT_BUILD_LBVH_GPU | abi.VKRT_BUILD_SAH_HOST, abi.VKRT_BUILD_PLOC_GPU | abi.VKRT_BUILD_LBVH_GPU, 0x8, 0x7):
+        assert r.lib.vkrt_accel_build(r._h, flags, None) == abi.VKRT_ERR_INVALID_ARGUMENT, flags
+    assert r.lib.vkrt_accel_build(r._h, 0, None) == 0 and r.accel_info()["build_flags"] == abi.VKRT_BUILD_PLOC_GPU
+    assert r.lib.vkrt_scene_set_option(r._h, 99, 1) == abi.VKRT_ERR_INVALID_ARGUMENT
     r.close()
 
 

@@ -39,6 +39,7 @@ def run(handles, subframes):
 
 
 out = {}
-for handles, sub in ((1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1)):
+configs = [tuple(int(v) for v in c.split(":")) for c in os.environ.get("PROBE_CONFIGS", "1:1,1:2,1:3,2:1,2:2,3:1,3:2,4:1").split(",")]
+for handles, sub in configs:
     out[f"handles{handles}_sub{sub}"] = round(run(handles, sub), 3)
     print(json.dumps(out), flush=True)

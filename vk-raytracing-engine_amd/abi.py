@@ -167,6 +167,7 @@ assert C.sizeof(GltfLight) == 32
 assert C.sizeof(PrimMesh) == 20
 assert C.sizeof(Node) == 68
 
+VKRT_OK, VKRT_ERR_INVALID_ARGUMENT, VKRT_ERR_NO_DEVICE, VKRT_ERR_HIP, VKRT_ERR_OUT_OF_MEMORY, VKRT_ERR_NOT_BUILT, VKRT_ERR_UNSUPPORTED = range(7)
 VKRT_BUILD_LBVH_GPU = 0x1
 VKRT_BUILD_SAH_HOST = 0x2
 VKRT_BUILD_PLOC_GPU = 0x4

@@ -74,7 +74,7 @@ class Renderer:
         """Size the working set for launches of this shard geometry (no allocation / host sync inside later pathtrace calls)."""
         _check(self.lib.vkrt_reserve(self._h, C.byref(shard), C.c_void_p(stream.cuda_stream) if stream is not None else None), "vkrt_reserve")
 
-    def build(self, kind="sah"):
+    def build(self, kind="ploc"):
         flags = {"sah": abi.VKRT_BUILD_SAH_HOST, "lbvh": abi.VKRT_BUILD_LBVH_GPU, "ploc": abi.VKRT_BUILD_PLOC_GPU}[kind]
         _check(self.lib.vkrt_accel_build(self._h, flags, None), "vkrt_accel_build")
         self.build_kind = kind
