@@ -26,7 +26,8 @@ def source_hash():
 
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(PKG_DIR, "csrc", "*.h")) + glob.glob(os.path.join(PKG_DIR, "csrc", "*.hip"))
-                   + glob.glob(os.path.join(PKG_DIR, "csrc", "*.cpp")) + glob.glob(os.path.join(REPO_ROOT, "include", "*.h")))
+                   + glob.glob(os.path.join(PKG_DIR, "csrc", "*.cpp")) + glob.glob(os.path.join(REPO_ROOT, "include", "*.h"))
+                   + [os.path.join(PKG_DIR, "csrc", "Makefile")])  # (the Makefile: compiler flags change the kernels too)
     for f in files:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
