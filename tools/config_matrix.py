@@ -87,7 +87,7 @@ def main():
     # ---- C2: cornell 720p, depth 4, 64 spp, LBVH build on the GPU
     W, H = 1280, 720
     cam = cam_for(W, H)
-    r = Renderer(cornell, device=0, build="lbvh")
+    r = Renderer(cornell, device=0, build="ploc")
     rows = np.unique(np.linspace(0, H - 1, a.cpu_rows).astype(np.uint32))
     res = {"build": r.accel_info() if hasattr(r, "accel_info") else None}
     # (a) 64 frames x 1 spp, seed = frame index
@@ -111,7 +111,7 @@ def main():
     flat, info = atrium.build_atrium(262144, seed=1)
     orc_a = oracle_py.OracleScene(flat, build_bvh=True, max_leaf=4)
     lights = len(flat.lights)
-    r = Renderer(flat, device=0, build="sah")
+    r = Renderer(flat, device=0, build="ploc")
     W, H = 1920, 1080
     cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
     rows = np.unique(np.linspace(0, H - 1, a.cpu_rows).astype(np.uint32))
