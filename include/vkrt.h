@@ -293,6 +293,20 @@ typedef struct vkrt_trace_timing {
 int vkrt_last_trace_timing(vkrt_scene* scene, vkrt_trace_timing* out);
 
 /* ---- test hooks (used by tests/ to compare single pieces with the oracle) ---------- */
+/* Structural check of the built acceleration structure (downloads it; host walk).  A tree is sound when every triangle slot
+ * is referenced by exactly one leaf, every node is reached exactly once from the root, and every triangle lies inside the
+ * decoded box of each of its ancestors' child slots (the quantised boxes are conservative).  Any builder, both layouts. */
+typedef struct vkrt_accel_check {
+  uint64_t nodes_reached;        /* == vkrt_accel_info.node_count */
+  uint64_t triangles_referenced; /* leaf references in total */
+  uint64_t triangles_missing;    /* slots no leaf references */
+  uint64_t triangles_repeated;   /* references beyond the first of a slot */
+  uint64_t box_violations;       /* (triangle, ancestor slot) pairs with a vertex outside the slot's box */
+  uint64_t bad_references;       /* child / triangle indices out of range, nodes reached twice */
+  uint32_t max_depth;            /* nodes on the longest root-to-leaf path */
+  uint32_t layout;               /* 1 = 8-wide compressed, 0 = BVH2 */
+} vkrt_accel_check;
+int vkrt_debug_check_accel(vkrt_scene* scene, vkrt_accel_check* out);
 /* Closest-hit query for n rays: o,d = vec3[n] host arrays; tmin/tmax scalars.
  * Writes t,u,v (float[n]) and the flattened triangle id gid (int32[n], -1 = miss). */
 int vkrt_debug_trace_rays(vkrt_scene* scene, uint32_t n, const float* origins,

@@ -106,6 +106,12 @@ class Shard(C.Structure):
     ]
 
 
+class AccelCheck(C.Structure):
+    _fields_ = [("nodes_reached", C.c_uint64), ("triangles_referenced", C.c_uint64), ("triangles_missing", C.c_uint64),
+                ("triangles_repeated", C.c_uint64), ("box_violations", C.c_uint64), ("bad_references", C.c_uint64),
+                ("max_depth", c_u), ("layout", c_u)]
+
+
 class TraceOpts(C.Structure):
     _fields_ = [("seed", c_u), ("flags", c_u)]
 
@@ -203,6 +209,7 @@ VKRT_SYMBOLS = [
     "vkrt_counters_read",
     "vkrt_last_trace_ms",
     "vkrt_last_trace_timing",
+    "vkrt_debug_check_accel",
     "vkrt_debug_trace_rays",
     "vkrt_debug_eval_math",
 ]
@@ -228,6 +235,8 @@ def declare_vkrt(lib):
     lib.vkrt_accel_build.restype = C.c_int
     lib.vkrt_accel_get_info.argtypes = [C.c_void_p, P(AccelInfo)]
     lib.vkrt_accel_get_info.restype = C.c_int
+    lib.vkrt_debug_check_accel.argtypes = [C.c_void_p, P(AccelCheck)]
+    lib.vkrt_debug_check_accel.restype = C.c_int
     lib.vkrt_shard_rows.argtypes = [P(Shard)]
     lib.vkrt_shard_rows.restype = c_u
     lib.vkrt_pathtrace.argtypes = [

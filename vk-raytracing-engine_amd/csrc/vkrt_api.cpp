@@ -1079,6 +1079,143 @@ int vkrt_debug_trace_rays(vkrt_scene* s, uint32_t n, const float* origins, const
   return VKRT_OK;
 }
 
+int vkrt_debug_check_accel(vkrt_scene* s, vkrt_accel_check* out)
+{
+  if(!s || !out)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(!s->built)
+    return fail(VKRT_ERR_NOT_BUILT, "vkrt_accel_build has not run");
+  int rc = setDevice(s);
+  if(rc != VKRT_OK)
+    return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  memset(out, 0, sizeof *out);
+  const uint32_t T = s->dev.triCount, N = s->info.node_count;
+  out->layout = s->dev.layout;
+  std::vector<float> tris((size_t)T * 12);
+  if(T)
+    HIP_TRY(hipMemcpy(tris.data(), s->accelTris, tris.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> seen(T, 0u);
+  std::vector<uint8_t> reached(N, 0);
+  struct Bound { float lo[3], hi[3]; };
+  std::vector<Bound> chain;  // boxes of the slots on the path from the root
+  auto checkTriangle = [&](uint32_t slot) {
+    out->triangles_referenced++;
+    if(slot >= T) { out->bad_references++; return; }
+    if(seen[slot]++) out->triangles_repeated++;
+    const float* t = &tris[(size_t)slot * 12];  // v0, e1, e2
+    for(int v = 0; v < 3; v++)
+    {
+      float p[3];
+      for(int k = 0; k < 3; k++)
+        p[k] = v == 0 ? t[k] : (v == 1 ? t[k] + t[3 + k] : t[k] + t[6 + k]);
+      for(const Bound& b : chain)
+        for(int k = 0; k < 3; k++)
+          if(!(p[k] >= b.lo[k] && p[k] <= b.hi[k])) { out->box_violations++; break; }
+    }
+  };
+  if(s->dev.layout == 1u)
+  {
+    std::vector<uint32_t> nodes((size_t)N * 20);
+    if(N)
+      HIP_TRY(hipMemcpy(nodes.data(), s->accelNodes, nodes.size() * 4, hipMemcpyDeviceToHost));
+    struct Item { uint32_t node, depth; size_t chainLen; Bound b; bool hasBound; };
+    std::vector<Item> stack;
+    if(s->dev.rootRef != VKRT_TRAV_DONE && N)
+      stack.push_back(Item{0u, 1u, 0, Bound{}, false});
+    while(!stack.empty())
+    {
+      const Item it = stack.back();
+      stack.pop_back();
+      chain.resize(it.chainLen);
+      if(it.hasBound) chain.push_back(it.b);
+      if(it.node >= N || reached[it.node]++) { out->bad_references++; continue; }
+      out->nodes_reached++;
+      out->max_depth = std::max(out->max_depth, it.depth);
+      const uint32_t* n = &nodes[(size_t)it.node * 20];
+      float org[3];
+      memcpy(org, n, 12);
+      const uint32_t ew = n[3], imask = ew >> 24, childBase = n[4], triBase = n[5];
+      double cell[3];
+      for(int k = 0; k < 3; k++) cell[k] = std::ldexp(1.0, (int)((ew >> (8 * k)) & 255u) - 127);
+      for(int slot = 0; slot < 8; slot++)
+      {
+        const uint32_t meta = (n[6 + (slot >> 2)] >> (8 * (slot & 3))) & 255u;
+        if(meta == 0u)
+        {
+          if(imask & (1u << slot)) out->bad_references++;
+          continue;
+        }
+        Bound b;
+        for(int k = 0; k < 3; k++)
+        {
+          const uint32_t ql = (n[8 + 2 * k + (slot >> 2)] >> (8 * (slot & 3))) & 255u;
+          const uint32_t qh = (n[14 + 2 * k + (slot >> 2)] >> (8 * (slot & 3))) & 255u;
+          b.lo[k] = (float)((double)org[k] + ql * cell[k]);  // (exact in double; the kernel pads its own float arithmetic)
+          b.hi[k] = (float)((double)org[k] + qh * cell[k]);
+          if((double)b.lo[k] > (double)org[k] + ql * cell[k]) b.lo[k] = std::nextafter(b.lo[k], -INFINITY);
+          if((double)b.hi[k] < (double)org[k] + qh * cell[k]) b.hi[k] = std::nextafter(b.hi[k], INFINITY);
+        }
+        const bool internal = (imask >> slot) & 1u;
+        if(internal)
+        {
+          if(meta != (0x20u | (24u + (uint32_t)slot))) out->bad_references++;
+          const uint32_t rank = (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u));
+          stack.push_back(Item{childBase + rank, it.depth + 1u, chain.size(), b, true});
+        }
+        else
+        {
+          const uint32_t unary = meta >> 5, off = meta & 31u;
+          const uint32_t cnt = (uint32_t)__builtin_popcount(unary);
+          if(unary != (1u << cnt) - 1u || cnt == 0u || off + cnt > 24u) out->bad_references++;
+          chain.push_back(b);
+          for(uint32_t t = 0; t < cnt; t++) checkTriangle(triBase + off + t);
+          chain.pop_back();
+        }
+      }
+    }
+  }
+  else
+  {
+    std::vector<float> nodes((size_t)N * 16);
+    if(N)
+      HIP_TRY(hipMemcpy(nodes.data(), s->accelNodes, nodes.size() * 4, hipMemcpyDeviceToHost));
+    struct Item { int32_t ref; uint32_t depth; size_t chainLen; Bound b; bool hasBound; };
+    std::vector<Item> stack;
+    if(s->dev.rootRef != VKRT_TRAV_DONE)
+      stack.push_back(Item{s->dev.rootRef, 1u, 0, Bound{}, false});
+    while(!stack.empty())
+    {
+      const Item it = stack.back();
+      stack.pop_back();
+      chain.resize(it.chainLen);
+      if(it.hasBound) chain.push_back(it.b);
+      if(it.ref < 0)
+      {  // leaf: ~(first slot << 3 | count - 1)
+        const uint32_t code = (uint32_t)~it.ref, first = code >> 3, cnt = (code & 7u) + 1u;
+        out->max_depth = std::max(out->max_depth, it.depth - 1u);
+        for(uint32_t t = 0; t < cnt; t++) checkTriangle(first + t);
+        continue;
+      }
+      if((uint32_t)it.ref >= N || reached[(uint32_t)it.ref]++) { out->bad_references++; continue; }
+      out->nodes_reached++;
+      out->max_depth = std::max(out->max_depth, it.depth);
+      const float* n = &nodes[(size_t)it.ref * 16];
+      for(int c = 0; c < 2; c++)
+      {
+        Bound b;
+        for(int k = 0; k < 3; k++) { b.lo[k] = n[6 * c + k]; b.hi[k] = n[6 * c + 3 + k]; }
+        int32_t ref;
+        memcpy(&ref, &n[12 + c], 4);
+        stack.push_back(Item{ref, it.depth + 1u, chain.size(), b, true});
+      }
+    }
+  }
+  for(uint32_t t = 0; t < T; t++)
+    if(!seen[t]) out->triangles_missing++;
+  return VKRT_OK;
+}
+
 int vkrt_debug_eval_math(int device, int op, uint32_t n, const float* a, const float* b, float* out)
 {
   if(n && (!a || !b || !out))

@@ -95,6 +95,13 @@ class Renderer:
         _check(self.lib.vkrt_accel_get_info(self._h, C.byref(info)), "vkrt_accel_get_info")
         return {n: getattr(info, n) for n, _ in info._fields_}
 
+    def check_accel(self):
+        """Structural check of the built tree (vkrt_debug_check_accel): dict of counts; a sound tree has every triangle once and
+        no violations."""
+        c = abi.AccelCheck()
+        _check(self.lib.vkrt_debug_check_accel(self._h, C.byref(c)), "vkrt_debug_check_accel")
+        return {n: getattr(c, n) for n, _ in c._fields_}
+
     def shard_rows(self, shard):
         return int(self.lib.vkrt_shard_rows(C.byref(shard)))
 
