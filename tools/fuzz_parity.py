@@ -1,0 +1,203 @@
+"""Randomised differential test: random small scenes (triangle soups + quads, instanced with arbitrary affine transforms, random
+PBR materials with random NPOT textures, point / directional / spot lights), random cameras, builders, options, sample counts and
+depths -- the HIP path tracer and the hybrid passes against the CPU oracle, bit for bit.
+
+    python tools/fuzz_parity.py [--seconds 300] [--seed 1] [--out gpurun_out/fuzz_parity.json]
+
+Bit-identity is the expectation for the path tracer (both sides follow one arithmetic profile and the image is a function of the
+triangle set); the hybrid planes may differ in isolated pixels where libm's exp2f / the G-buffer's float rounding feed a
+quantisation boundary, so those are compared by mismatch fraction.  Every failing case prints its seed for replay (--only SEED)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+
+import vkrt_amd  # noqa: F401
+from vkrt_amd import abi
+from vkrt_amd.flat_scene import LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, FlatScene, make_push_constants, uniforms_from_matrices
+from vkrt_amd.renderer import Renderer
+import camera_np
+import oracle_py
+
+
+def random_scene(rng):
+    meshes = []
+    n_mesh = int(rng.integers(1, 4))
+    for _ in range(n_mesh):
+        kind = rng.integers(0, 3)
+        if kind == 0:  # soup
+            n = int(rng.integers(1, 400))
+            c = rng.uniform(-2, 2, (n, 1, 3))
+            P = (c + rng.normal(0, rng.choice([0.05, 0.3, 1.0]), (n, 3, 3))).reshape(-1, 3)
+            idx = np.arange(3 * n)
+        elif kind == 1:  # grid (shared vertices, coplanar neighbours: edge and tie cases)
+            g = int(rng.integers(1, 12))
+            xs = np.linspace(-2, 2, g + 1)
+            gx, gz = np.meshgrid(xs, xs)
+            P = np.stack([gx.ravel(), rng.normal(0, 0.02, gx.size) * rng.integers(0, 2), gz.ravel()], -1)
+            idx = []
+            for j in range(g):
+                for i in range(g):
+                    a = j * (g + 1) + i
+                    idx += [a, a + g + 1, a + 1, a + 1, a + g + 1, a + g + 2]
+            idx = np.array(idx)
+        else:  # box-ish shell of big triangles
+            c = rng.uniform(-1, 1, (8, 3)) * 0.2 + np.array([[x, y, z] for x in (-3, 3) for y in (-2, 3) for z in (-3, 3)])
+            P = c
+            idx = np.array([0, 1, 2, 1, 3, 2, 4, 6, 5, 5, 6, 7, 0, 4, 1, 1, 4, 5, 2, 3, 6, 3, 7, 6, 0, 2, 4, 2, 6, 4, 1, 5, 3, 3, 5, 7])
+        if rng.random() < 0.15 and idx.size >= 6:
+            idx = idx[: idx.size - int(rng.integers(1, 3))]  # ragged index count (hello_vulkan.cpp:960-969)
+        nrm = rng.normal(size=P.shape)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        tan = np.concatenate([np.roll(nrm, 1, axis=1), np.where(rng.random((P.shape[0], 1)) < 0.5, 1.0, -1.0)], 1)
+        uv = rng.uniform(-1, 3, (P.shape[0], 2))
+        meshes.append((P.astype(np.float32), nrm.astype(np.float32), tan.astype(np.float32), uv.astype(np.float32), idx.astype(np.uint32)))
+    n_tex = int(rng.integers(0, 5))
+    textures = []
+    for _ in range(n_tex):
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        textures.append({"rgba8": rng.integers(0, 256, (h, w, 4), dtype=np.uint8), "is_srgb": bool(rng.random() < 0.5)})
+    n_mat = int(rng.integers(1, 5))
+    mats = np.zeros(n_mat, MAT_DTYPE)
+    for m in mats:
+        m["pbrBaseColorFactor"] = [*rng.uniform(0.05, 1.0, 3), 1.0]
+        for key in ("pbrBaseColorTexture", "metallicRoughnessTexture", "normalTexture", "emissiveTexture"):
+            m[key] = int(rng.integers(0, n_tex)) if (n_tex and rng.random() < 0.5) else -1
+        m["metallicFactor"] = rng.choice([0.0, 1.0, rng.random()])
+        m["roughnessFactor"] = rng.choice([0.0, 1.0, rng.random()])
+        m["emissiveFactor"] = rng.uniform(0, 2, 3) * (rng.random() < 0.4)
+    pos = np.concatenate([m[0] for m in meshes]); nrm = np.concatenate([m[1] for m in meshes])
+    tan = np.concatenate([m[2] for m in meshes]); uv = np.concatenate([m[3] for m in meshes])
+    idx = np.concatenate([m[4] for m in meshes])
+    pm = np.zeros(n_mesh, PRIM_DTYPE)
+    vo = io = 0
+    for k, m in enumerate(meshes):
+        pm[k] = (io, m[4].size, vo, m[0].shape[0], int(rng.integers(-1, n_mat)))
+        vo += m[0].shape[0]; io += m[4].size
+    n_nodes = int(rng.integers(1, 6))
+    nodes = np.zeros(n_nodes, NODE_DTYPE)
+    for nd in nodes:
+        M = np.eye(4)
+        if rng.random() < 0.7:
+            A = rng.normal(size=(3, 3))
+            Q, _ = np.linalg.qr(A)
+            S = np.diag(rng.uniform(0.3, 2.0, 3) * np.where(rng.random(3) < 0.15, -1.0, 1.0))
+            M[:3, :3] = Q @ S
+            M[:3, 3] = rng.uniform(-2, 2, 3)
+        nd["worldMatrix"] = M.T.astype(np.float32).ravel()  # column-major storage
+        nd["primMesh"] = int(rng.integers(0, n_mesh))
+    n_l = int(rng.integers(1, 5))
+    lights = np.zeros(n_l, LIGHT_DTYPE)
+    for l in lights:
+        l["position"] = rng.uniform(-4, 4, 3)
+        l["color"] = rng.uniform(0, 1, 3)
+        l["intensity"] = rng.uniform(0.5, 60)
+        l["type"] = int(rng.integers(0, 3))
+    return FlatScene(pos, nrm, tan, uv, idx, pm, mats, lights, nodes, textures)
+
+
+def run_case(seed, verbose=False):
+    rng = np.random.default_rng(seed)
+    flat = random_scene(rng)
+    W, H = int(rng.integers(8, 64)), int(rng.integers(8, 48))
+    eye = rng.uniform(-5, 5, 3); center = rng.uniform(-1, 1, 3)
+    cam = uniforms_from_matrices(*camera_np.global_uniforms(width=W, height=H, eye=tuple(eye), center=tuple(center), up=(0, 1, 0), fov=float(rng.uniform(20, 100))))
+    kind = str(rng.choice(["sah", "lbvh", "ploc"]))
+    opts = {}
+    if rng.random() < 0.2: opts[abi.VKRT_OPT_BVH_LAYOUT] = 0
+    if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SHARE] = int(rng.choice([0, 4, 40]))
+    if rng.random() < 0.15: opts[abi.VKRT_OPT_MODE] = 0
+    if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SUBFRAMES] = int(rng.integers(1, 5))
+    spp, depth, frames = int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(1, 3))
+    L = int(rng.integers(1, len(flat.lights) + 1))
+    flags = abi.VKRT_TRACE_SEED_INDEX_ROW_MAJOR if rng.random() < 0.5 else 0
+    info = dict(seed=seed, tris=flat.instanced_triangle_count, size=(W, H), kind=kind, opts={int(k): int(v) for k, v in opts.items()}, spp=spp, depth=depth, frames=frames)
+    orc = oracle_py.OracleScene(flat)
+    r = Renderer(flat, device=0, build=kind, options=opts)
+    problems = []
+    try:
+        img = ref = None
+        for f in range(frames):
+            pc = make_push_constants(samples=spp, depth=depth, frame=f, lights_count=L)
+            img = r.pathtrace(pc, cam, W, H, seed=seed + f, flags=flags, image=img)
+            ref, _ = orc.render(pc, cam, W, H, seed=seed + f, flags=flags, image=ref)
+        got = img.cpu().numpy()
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        if not same.all():
+            problems.append(("pathtrace", float(1 - same.all(-1).mean()), float(np.nanmax(np.abs(got - ref)))))
+        c = r.counters()
+        info["rays"] = int(c["rays_closest"] + c["rays_shadow"])
+        info["lit"] = float((np.nan_to_num(got[..., :3]).sum(-1) > 0).mean())
+        if c["traversal_faults"]:
+            problems.append(("faults", c["traversal_faults"], 0))
+        chk = r.check_accel()
+        if chk["triangles_missing"] or chk["triangles_repeated"] or chk["box_violations"] or chk["bad_references"]:
+            problems.append(("tree", chk, 0))
+        # hybrid passes
+        g = r.gbuffer_raycast(cam, W, H, lights_count=L)
+        gref = orc.gbuffer(cam, W, H, lights_count=L)
+        for k in gref:
+            a, b = g[k].cpu().numpy(), gref[k]
+            bad = ((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))).any(-1).mean()
+            if bad > 0.02:
+                problems.append(("gbuffer_" + k, float(bad), float(np.nanmax(np.abs(a - b)))))
+        pc = make_push_constants(samples=1, depth=max(depth, 2), frame=0, lights_count=L)
+        pc.useShadows, pc.useAO, pc.useGI = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        gnp = {k: v.cpu().numpy() for k, v in g.items()}
+        acc = r.hybrid_trace(pc, cam, W, H, g, seed=seed, flags=flags).cpu().numpy()
+        accr, _ = orc.hybrid(pc, cam, W, H, gnp, seed=seed, flags=flags)
+        bad = ((acc.view(np.uint32) != accr.view(np.uint32)) & ~(np.isnan(acc) & np.isnan(accr))).any(-1).mean()
+        if bad > 0.0:
+            problems.append(("hybrid", float(bad), float(np.nanmax(np.abs(acc - accr)))))
+    finally:
+        r.close()
+    if verbose or problems:
+        print(json.dumps({**info, "problems": problems}, default=str), flush=True)
+    return info, problems
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=None, help="replay one case")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"))
+    a = ap.parse_args()
+    if a.only is not None:
+        run_case(a.only, verbose=True)
+        return 0
+    t0 = time.time()
+    n = bad = 0
+    failures = []
+    tris = rays = 0
+    lit = 0.0
+    while time.time() - t0 < a.seconds:
+        seed = a.seed * 1000003 + n
+        try:
+            info, problems = run_case(seed)
+        except Exception as e:  # an API error is a finding too
+            info, problems = dict(seed=seed), [("exception", repr(e), 0)]
+            print(json.dumps({"seed": seed, "exception": repr(e)}), flush=True)
+        n += 1
+        tris += info.get("tris", 0)
+        rays += info.get("rays", 0)
+        lit += info.get("lit", 0.0)
+        if problems:
+            bad += 1
+            failures.append({**info, "problems": problems})
+        if n % 50 == 0:
+            print(f"[{time.time() - t0:6.0f} s] {n} cases, {bad} with findings", flush=True)
+    out = {"cases": n, "with_findings": bad, "seconds": round(time.time() - t0, 1), "triangles_total": tris, "rays_total": rays, "mean_lit_pixel_fraction": round(lit / max(n, 1), 3), "first_seed": a.seed * 1000003, "failures": failures[:50]}
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(out, open(a.out, "w"), indent=1, default=str)
+    print(json.dumps({k: v for k, v in out.items() if k != "failures"}))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
