@@ -223,7 +223,7 @@ int vkrt_reserve(vkrt_scene* scene, const vkrt_shard* shard, void* hip_stream);
  * run parts of a frame on internal streams that fork from and join `hip_stream` through events).  No host
  * synchronisation happens inside the call once the working set is large enough (vkrt_reserve above).  pc->frame > 0 blends into the image the caller kept from the previous
  * frame (raytrace.rgen:136-145), so the image buffer is caller-owned and persistent.  Calls on one scene handle must
- * be serialised by the caller. */
+ * be serialised by the caller.  A shard without rows (more shards than strips) is a no-op and may pass NULL buffers. */
 int vkrt_pathtrace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam,
                    const vkrt_trace_opts* opts, const vkrt_shard* shard,
                    float* rgba32f_device, void* hip_stream);

@@ -224,6 +224,12 @@ def test_error_paths(cornell_flat):
         assert r.lib.vkrt_accel_build(r._h, flags, None) == abi.VKRT_ERR_INVALID_ARGUMENT, flags
     assert r.lib.vkrt_accel_build(r._h, 0, None) == 0 and r.accel_info()["build_flags"] == abi.VKRT_BUILD_PLOC_GPU
     assert r.lib.vkrt_scene_set_option(r._h, 99, 1) == abi.VKRT_ERR_INVALID_ARGUMENT
+    # a shard without rows (more shards than 16-row strips) is a no-op, also with nothing to write to
+    empty = abi.Shard(32, 32, 16, 5, 4)
+    assert r.shard_rows(empty) == 0
+    out = r.pathtrace(make_push_constants(lights_count=1), cam, 32, 32, shard=empty)
+    assert out.shape == (0, 32, 4)
+    assert r.gbuffer_raycast(cam, 32, 32, lights_count=1, shard=empty)["color"].shape == (0, 32, 4)
     r.close()
 
 

@@ -138,6 +138,17 @@ def run_case(seed, verbose=False):
         chk = r.check_accel()
         if chk["triangles_missing"] or chk["triangles_repeated"] or chk["box_violations"] or chk["bad_references"]:
             problems.append(("tree", chk, 0))
+        if rng.random() < 0.35 and abi.VKRT_OPT_MODE not in opts:  # a random image-strip shard equals the rows of the whole frame
+            count = int(rng.integers(2, 6)); index = int(rng.integers(0, count)); strip = int(rng.choice([1, 3, 16]))
+            sh = abi.Shard(W, H, strip, count, index)
+            rows = [y for y in range(H) if (y // strip) % count == index]
+            part = None
+            for f in range(frames):
+                pc = make_push_constants(samples=spp, depth=depth, frame=f, lights_count=L)
+                part = r.pathtrace(pc, cam, W, H, seed=seed + f, flags=flags, image=part, shard=sh)
+            part = part.cpu().numpy()
+            if part.shape[0] != len(rows) or not np.array_equal(part.view(np.uint32), got[rows].view(np.uint32)):
+                problems.append(("shard", (count, index, strip), 0))
         # hybrid passes
         g = r.gbuffer_raycast(cam, W, H, lights_count=L)
         gref = orc.gbuffer(cam, W, H, lights_count=L)

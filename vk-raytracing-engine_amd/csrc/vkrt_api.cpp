@@ -726,8 +726,10 @@ uint32_t vkrt_shard_rows(const vkrt_shard* sh)
 int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts,
                    const vkrt_shard* shard, float* image, void* hip_stream)
 {
-  if(!s || !pc || !cam || !shard || !image)
+  if(!s || !pc || !cam || !shard)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(!image && vkrt_shard_rows(shard) != 0u)  // (a shard without rows -- more ranks than strips -- has no image to pass)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL image");
   if(!s->built)
     return fail(VKRT_ERR_NOT_BUILT, "vkrt_pathtrace before vkrt_accel_build");
   if(shard->full_width == 0 || shard->full_height == 0)
@@ -893,6 +895,8 @@ namespace {
 int gbufferImpl(vkrt_scene* s, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const float* viewMatrix, const vkrt_shard* shard,
                 const vkrt_gbuffer* out, const vkrt_nrd_planes* nrd, void* hip_stream)
 {
+  if(s && clearColor && cam && shard && out && vkrt_shard_rows(shard) == 0u)
+    return VKRT_OK;  // a shard without rows: nothing to write, no planes to pass
   if(!s || !clearColor || !cam || !shard || !out || !out->color || !out->position || !out->normal || !out->roughMetal)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
   if(lightsCount < 0 || (uint32_t)lightsCount > s->lightCount)
@@ -920,6 +924,8 @@ int gbufferImpl(vkrt_scene* s, const float clearColor[4], int lightsCount, const
 int hybridImpl(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
                const vkrt_gbuffer* g, const vkrt_nrd_planes* nrd, float* accum, void* hip_stream)
 {
+  if(s && pc && cam && shard && g && vkrt_shard_rows(shard) == 0u)
+    return VKRT_OK;
   if(!s || !pc || !cam || !shard || !g || !accum || !g->color || !g->position || !g->normal || !g->roughMetal)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
   if(pc->lightsCount < 0 || (uint32_t)pc->lightsCount > s->lightCount)
