@@ -151,6 +151,28 @@ def run_case(seed, verbose=False):
             part = part.cpu().numpy()
             if part.shape[0] != len(rows) or not np.array_equal(part.view(np.uint32), got[rows].view(np.uint32)):
                 problems.append(("shard", (count, index, strip), 0))
+        if rng.random() < 0.1:  # the C++ host end to end: file -> loader -> HelloVkrt -> image, against the oracle on the numpy ingest
+            import tempfile
+            import gltf_export
+            import gltf_flatten
+            from vkrt_amd import host_py
+            with tempfile.TemporaryDirectory() as tmp:
+                mode = int(rng.integers(0, 3))
+                path = os.path.join(tmp, "s.glb" if mode == 1 else "s.gltf")
+                gltf_export.export_gltf(flat, path, glb=(mode == 1), embed=(mode == 2), write_lights=True)
+                cfg = dict(eye=tuple(float(v) for v in eye), center=tuple(float(v) for v in center), up=(0, 1, 0), fov=float(rng.uniform(20, 100)))
+                bf = {"sah": abi.VKRT_BUILD_SAH_HOST, "lbvh": abi.VKRT_BUILD_LBVH_GPU, "ploc": abi.VKRT_BUILD_PLOC_GPU}[kind]
+                himg = host_py.render_gltf(path, W, H, samples=spp, depth=depth, frames=frames, seed0=seed, build=bf, **cfg)
+                f2 = gltf_flatten.load_gltf(path)
+                o2 = oracle_py.OracleScene(f2)
+                u2 = host_py.global_uniforms(width=W, height=H, **cfg)
+                href = None
+                for f in range(frames):
+                    pc = make_push_constants(samples=spp, depth=depth, frame=f, lights_count=len(f2.lights))
+                    href, _ = o2.render(pc, u2, W, H, seed=seed + f, image=href)
+                ok = (himg.view(np.uint32) == href.view(np.uint32)) | (np.isnan(himg) & np.isnan(href))
+                if not ok.all():
+                    problems.append(("cpp_host", float(1 - ok.all(-1).mean()), float(np.nanmax(np.abs(himg - href)))))
         # hybrid passes (with the NRD front-end planes in a third of the cases)
         vm = None
         if rng.random() < 0.33:
