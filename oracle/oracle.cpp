@@ -332,14 +332,24 @@ inline float safe_inv(float d)
 // Conservative slab test: true if [tnear,tfar] overlaps [tmin,tmax].  Slabs widened by 2e-5 * max(|t0|,|t1|) per axis and the
 // far side by a relative 4e-5 -- the margin covers the rounding of the slab arithmetic (Ize 2013) AND of the triangle test,
 // which can accept a ray just outside the exact triangle; with these margins BVH and brute force agree (see test_oracle.py).
+// Round 2 (found by tools/fuzz_parity.py on a scene with a 500-unit triangle): the triangle test's error in t grows with the
+// distance |o - v0| in ALL axes (times 1 / cos of the incidence), not with the distance along the slab's own axis, and it can
+// carry a hit across tmin / tmax that the box test had clamped away.  So every axis' pad also covers 2e-5 x the largest
+// distance from the origin to the box in any axis (times that axis' |1/d|, capped for near-parallel axes whose slabs are
+// decided by their own huge t), and the [tmin, tmax] clamp is relaxed by the largest pad.
 inline bool isect_box(const RayInv& r, const Aabb& b, float tmin, float tmax, float& tnear)
 {
   float t0x = (b.lo[0] - r.o.x) * r.id.x, t1x = (b.hi[0] - r.o.x) * r.id.x;
   float t0y = (b.lo[1] - r.o.y) * r.id.y, t1y = (b.hi[1] - r.o.y) * r.id.y;
   float t0z = (b.lo[2] - r.o.z) * r.id.z, t1z = (b.hi[2] - r.o.z) * r.id.z;
-  float px = 2.0e-5f * fmaxf(fabsf(t0x), fabsf(t1x)), py = 2.0e-5f * fmaxf(fabsf(t0y), fabsf(t1y)), pz = 2.0e-5f * fmaxf(fabsf(t0z), fabsf(t1z));
-  float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin));
-  float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax));
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(b.lo[0] - r.o.x), fabsf(b.hi[0] - r.o.x)), fmaxf(fabsf(b.lo[1] - r.o.y), fabsf(b.hi[1] - r.o.y))),
+                        fmaxf(fabsf(b.lo[2] - r.o.z), fabsf(b.hi[2] - r.o.z)));
+  const float cx = m * fminf(fabsf(r.id.x), 1.0e4f), cy = m * fminf(fabsf(r.id.y), 1.0e4f), cz = m * fminf(fabsf(r.id.z), 1.0e4f);
+  float px = 2.0e-5f * fmaxf(fmaxf(fabsf(t0x), fabsf(t1x)), cx), py = 2.0e-5f * fmaxf(fmaxf(fabsf(t0y), fabsf(t1y)), cy),
+        pz = 2.0e-5f * fmaxf(fmaxf(fabsf(t0z), fabsf(t1z)), cz);
+  const float pc = 2.0e-5f * fmaxf(cx, fmaxf(cy, cz));  // slack of the [tmin, tmax] clamp
+  float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin - pc));
+  float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax + pc));
   tnear = tn;
   return tn <= tf * 1.00004f;
 }

@@ -66,8 +66,18 @@ VKRT_DEV float unionArea(const float* a, const float* b)  // a, b: lo[3] hi[3]
   return dx * dy + dy * dz + dz * dx;
 }
 
+// metric < 0: no search -- every cluster picks position i ^ 1 (all pairs are mutual).  The pass after one that merged nothing:
+// the cost above is symmetric in exact arithmetic only; cancellation (areas of 1e6 next to 1e-6, huge counts) can leave a
+// window without any mutual pair, and the loop must still shrink the array.
 __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int nc, int radius, int metric, const PlocCluster* __restrict__ c, int* __restrict__ nn)
 {
+  if(metric < 0)
+  {
+    const int i = (int)(blockIdx.x * PLOC_BLOCK + threadIdx.x);
+    if(i < nc)
+      nn[i] = (i ^ 1) < nc ? (i ^ 1) : -1;
+    return;
+  }
   __shared__ float box[(PLOC_BLOCK + 2 * PLOC_MAX_RADIUS) * 6];
   __shared__ float own[(PLOC_BLOCK + 2 * PLOC_MAX_RADIUS) * 2];  // own area, triangle count
   const int first = (int)(blockIdx.x * PLOC_BLOCK) - radius;  // position of box[0]
@@ -276,10 +286,11 @@ int ploc_cluster_device(uint32_t T, const unsigned* order, const float* triBox, 
   int nextId = (int)T - 2;
   int cur = 0;
   unsigned pass = 0;
+  bool forcePairs = false;
   while(nc > 1)
   {
     const unsigned blocks = (nc + PLOC_BLOCK - 1) / PLOC_BLOCK;
-    hipLaunchKernelGGL(k_ploc_nn, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, radius, metric, (const PlocCluster*)cl[cur], nn);
+    hipLaunchKernelGGL(k_ploc_nn, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, radius, forcePairs ? -1 : metric, (const PlocCluster*)cl[cur], nn);
     hipLaunchKernelGGL(k_ploc_count, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, (const int*)nn, blockCounts);
     hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, stream, blocks, blockCounts, totals);
     hipLaunchKernelGGL(k_ploc_apply, dim3(blocks), dim3(PLOC_BLOCK), 0, stream, (int)nc, nextId, (const int*)nn, (const PlocCluster*)cl[cur],
@@ -288,11 +299,12 @@ int ploc_cluster_device(uint32_t T, const unsigned* order, const float* triBox, 
     unsigned h[2];
     PLOC_TRY(hipMemcpyAsync(h, totals, 8, hipMemcpyDeviceToHost, stream));
     PLOC_TRY(hipStreamSynchronize(stream));
-    if(h[1] == 0u || h[0] != nc - h[1] || (int)h[1] > nextId + 1)
+    if((h[1] == 0u && forcePairs) || h[0] != nc - h[1] || (int)h[1] > nextId + 1)
     {
       err = "PLOC pass without progress (internal error)";
       return VKRT_ERR_HIP;
     }
+    forcePairs = h[1] == 0u;  // nothing merged (no mutual pair under rounding): pair neighbours in the next pass
     nc = h[0];
     nextId -= (int)h[1];
     cur ^= 1;

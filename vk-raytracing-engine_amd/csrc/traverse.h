@@ -38,9 +38,16 @@ VKRT_DEV bool box_test(f3 o, f3 id, float lox, float loy, float loz, float hix, 
   float t0x = (lox - o.x) * id.x, t1x = (hix - o.x) * id.x;
   float t0y = (loy - o.y) * id.y, t1y = (hiy - o.y) * id.y;
   float t0z = (loz - o.z) * id.z, t1z = (hiz - o.z) * id.z;
-  float px = VKRT_BOX_PAD_ABS * fmaxf(fabsf(t0x), fabsf(t1x)), py = VKRT_BOX_PAD_ABS * fmaxf(fabsf(t0y), fabsf(t1y)), pz = VKRT_BOX_PAD_ABS * fmaxf(fabsf(t0z), fabsf(t1z));
-  float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin));
-  float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax));
+  // (round 2, tools/fuzz_parity.py: the triangle test's error in t scales with the distance to the triangle in ALL axes and can
+  //  carry a hit across the tmin / tmax clamp: every pad also covers the largest origin-to-box distance of any axis, and the clamp
+  //  is relaxed by the largest pad; same formula as the oracle's tree walk)
+  const float m = fmaxf(fmaxf(fmaxf(fabsf(lox - o.x), fabsf(hix - o.x)), fmaxf(fabsf(loy - o.y), fabsf(hiy - o.y))), fmaxf(fabsf(loz - o.z), fabsf(hiz - o.z)));
+  const float cx = m * fminf(fabsf(id.x), 1.0e4f), cy = m * fminf(fabsf(id.y), 1.0e4f), cz = m * fminf(fabsf(id.z), 1.0e4f);
+  float px = VKRT_BOX_PAD_ABS * fmaxf(fmaxf(fabsf(t0x), fabsf(t1x)), cx), py = VKRT_BOX_PAD_ABS * fmaxf(fmaxf(fabsf(t0y), fabsf(t1y)), cy),
+        pz = VKRT_BOX_PAD_ABS * fmaxf(fmaxf(fabsf(t0z), fabsf(t1z)), cz);
+  const float pc = VKRT_BOX_PAD_ABS * fmaxf(cx, fmaxf(cy, cz));
+  float tn = fmaxf(fmaxf(fminf(t0x, t1x) - px, fminf(t0y, t1y) - py), fmaxf(fminf(t0z, t1z) - pz, tmin - pc));
+  float tf = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tmax + pc));
   tnear = tn;
   return tn <= tf * VKRT_BOX_PAD_REL;
 }
