@@ -105,6 +105,8 @@ def random_scene(rng):
             M[:3, 3] = rng.uniform(-2, 2, 3)
         nd["worldMatrix"] = M.T.astype(np.float32).ravel()  # column-major storage
         nd["primMesh"] = int(rng.integers(0, n_mesh))
+    if n_nodes > 1 and rng.random() < 0.1:  # the same instance twice: every triangle coincides with one of another gid (tie rule)
+        nodes[1] = nodes[0]
     n_l = int(rng.integers(1, 5))
     lights = np.zeros(n_l, LIGHT_DTYPE)
     for l in lights:
@@ -141,6 +143,12 @@ def run_case(seed, verbose=False):
     if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SUBFRAMES] = int(rng.integers(1, 5))
     spp, depth, frames = int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(1, 3))
     L = int(rng.integers(1, len(flat.lights) + 1))
+    edge = rng.random()
+    if edge < 0.02: spp = 0          # degenerate launches: the pixel is resolved without a ray
+    elif edge < 0.04: depth = 0
+    elif edge < 0.06: L = 0          # the light pick then always reads light 0 (int(rnd * 0))
+    elif edge < 0.08: W, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    first_frame = int(rng.integers(0, 3)) if rng.random() < 0.2 else 0  # start a sequence at frame > 0 (jittered from the first launch on)
     flags = abi.VKRT_TRACE_SEED_INDEX_ROW_MAJOR if rng.random() < 0.5 else 0
     info = dict(seed=seed, tris=flat.instanced_triangle_count, size=(W, H), kind=kind, opts={int(k): int(v) for k, v in opts.items()}, spp=spp, depth=depth, frames=frames)
     orc = oracle_py.OracleScene(flat)
@@ -149,7 +157,7 @@ def run_case(seed, verbose=False):
     brute = bool(rng.random() < 0.3) and W * H * spp * frames < 6000  # the oracle's loop over all triangles as the referee
     try:
         img = ref = None
-        for f in range(frames):
+        for f in range(first_frame, first_frame + frames):
             pc = make_push_constants(samples=spp, depth=depth, frame=f, lights_count=L)
             img = r.pathtrace(pc, cam, W, H, seed=seed + f, flags=flags, image=img)
             ref, _ = orc.render(pc, cam, W, H, seed=seed + f, flags=flags, image=ref, use_bvh=not brute)
@@ -159,7 +167,7 @@ def run_case(seed, verbose=False):
             # referee: the oracle's loop over all triangles.  (Needle triangles hundreds of units long make the triangle test accept
             # points centimetres outside the triangle; the oracle's own tree walk, with per-leaf boxes, can prune such a "hit".)
             ref = None
-            for f in range(frames):
+            for f in range(first_frame, first_frame + frames):
                 pc = make_push_constants(samples=spp, depth=depth, frame=f, lights_count=L)
                 ref, _ = orc.render(pc, cam, W, H, seed=seed + f, flags=flags, image=ref, use_bvh=False)
             same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
@@ -179,13 +187,13 @@ def run_case(seed, verbose=False):
             sh = abi.Shard(W, H, strip, count, index)
             rows = [y for y in range(H) if (y // strip) % count == index]
             part = None
-            for f in range(frames):
+            for f in range(first_frame, first_frame + frames):
                 pc = make_push_constants(samples=spp, depth=depth, frame=f, lights_count=L)
                 part = r.pathtrace(pc, cam, W, H, seed=seed + f, flags=flags, image=part, shard=sh)
             part = part.cpu().numpy()
             if part.shape[0] != len(rows) or not np.array_equal(part.view(np.uint32), got[rows].view(np.uint32)):
                 problems.append(("shard", (count, index, strip), 0))
-        if rng.random() < 0.1:  # the C++ host end to end: file -> loader -> HelloVkrt -> image, against the oracle on the numpy ingest
+        if rng.random() < 0.1 and first_frame == 0 and spp > 0 and depth > 0 and L == len(flat.lights):  # the C++ host end to end: file -> loader -> HelloVkrt -> image, against the oracle on the numpy ingest
             import tempfile
             import gltf_export
             import gltf_flatten
@@ -212,15 +220,15 @@ def run_case(seed, verbose=False):
         if rng.random() < 0.33:
             vi = np.asarray(cam.viewInverse.m[:], np.float64).reshape(4, 4).T  # column-major storage -> matrix
             vm = np.linalg.inv(vi).T.astype(np.float32).ravel()
-        g = r.gbuffer_raycast(cam, W, H, lights_count=L, view_matrix=vm)
-        gref = orc.gbuffer(cam, W, H, lights_count=L) if vm is None else orc.gbuffer_nrd(cam, vm, W, H, lights_count=L)
+        g = r.gbuffer_raycast(cam, W, H, lights_count=max(L, 1), view_matrix=vm)
+        gref = orc.gbuffer(cam, W, H, lights_count=max(L, 1)) if vm is None else orc.gbuffer_nrd(cam, vm, W, H, lights_count=max(L, 1))
         for k in gref:
             a, b = g[k].cpu().numpy(), gref[k]
             diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
             bad = diff.reshape(diff.shape[0], diff.shape[1], -1).any(-1).mean()
             if bad > 0.02:
                 problems.append(("gbuffer_" + k, float(bad), float(np.nanmax(np.abs(a - b)))))
-        pc = make_push_constants(samples=1, depth=max(depth, 2), frame=0, lights_count=L)
+        pc = make_push_constants(samples=1, depth=max(depth, 2), frame=0, lights_count=max(L, 1))
         pc.useShadows, pc.useAO, pc.useGI = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
         gnp = {k: v.cpu().numpy() for k, v in g.items()}
         acc = r.hybrid_trace(pc, cam, W, H, g, seed=seed, flags=flags).cpu().numpy()
