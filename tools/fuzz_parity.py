@@ -32,6 +32,8 @@ def random_scene(rng):
         kind = rng.integers(0, 3)
         if kind == 0:  # soup
             n = int(rng.integers(1, 400))
+            if rng.random() < 0.04:  # now and then large enough for the SAH top of the clustered build (> 4096 triangles) and its binned ranges
+                n = int(rng.integers(5000, 60000))
             c = rng.uniform(-2, 2, (n, 1, 3))
             P = (c + rng.normal(0, rng.choice([0.05, 0.3, 1.0]), (n, 3, 3))).reshape(-1, 3)
             idx = np.arange(3 * n)

@@ -497,7 +497,7 @@ struct TopBuilder
         if(lc == 0 || rc[k] == 0)
           continue;
         const float c = area(left) * (float)lc + ra[k] * (float)rc[k];
-        if(c < best)
+        if(c < best || (c == best && bestAxis == axis && std::abs(k - kBins / 2) < std::abs(bestBin - kBins / 2)))
         {
           best = c; bestAxis = axis; bestBin = k;
         }
@@ -557,7 +557,9 @@ struct TopBuilder
         grow(left, e[a + k - 1].box);
         lc += e[a + k - 1].count;
         const float c = area(left) * (float)lc + rightArea[k] * (float)rightCount[k];
-        if(c < best)
+        // equal costs (identical boxes: a pile of coincident triangles) must not peel one entry per level: prefer the middle
+        const size_t offMid = k > n / 2 ? k - n / 2 : n / 2 - k, bestOff = bestSplit > n / 2 ? bestSplit - n / 2 : n / 2 - bestSplit;
+        if(c < best || (c == best && offMid < bestOff))
         {
           best = c; bestAxis = axis; bestSplit = k;
         }
