@@ -228,7 +228,7 @@ def run_case(seed, verbose=False):
             a, b = g[k].cpu().numpy(), gref[k]
             diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
             bad = diff.reshape(diff.shape[0], diff.shape[1], -1).any(-1).mean()
-            if bad > 0.02:
+            if bad > (0.02 if k.startswith("nrd") else 0.0):  # (the NRD planes are quantised: a boundary now and then; the G-buffer itself must be exact)
                 problems.append(("gbuffer_" + k, float(bad), float(np.nanmax(np.abs(a - b)))))
         pc = make_push_constants(samples=1, depth=max(depth, 2), frame=0, lights_count=max(L, 1))
         pc.useShadows, pc.useAO, pc.useGI = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
