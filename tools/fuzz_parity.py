@@ -234,6 +234,19 @@ def run_case(seed, verbose=False):
         pc.useShadows, pc.useAO, pc.useGI = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
         gnp = {k: v.cpu().numpy() for k, v in g.items()}
         acc = r.hybrid_trace(pc, cam, W, H, g, seed=seed, flags=flags).cpu().numpy()
+        if rng.random() < 0.25:  # the hybrid passes of a random image-strip shard are the rows of the whole frame
+            count = int(rng.integers(2, 5)); index = int(rng.integers(0, count)); strip = int(rng.choice([2, 16]))
+            sh = abi.Shard(W, H, strip, count, index)
+            rows = [y for y in range(H) if (y // strip) % count == index]
+            gp = r.gbuffer_raycast(cam, W, H, lights_count=max(L, 1), view_matrix=vm, shard=sh)
+            wrong = [k for k in gp if not np.array_equal(gp[k].cpu().numpy().view(np.uint32), gnp[k][rows].view(np.uint32))]  # (before the trace packs the radiance plane)
+            accp = r.hybrid_trace(pc, cam, W, H, gp, seed=seed, flags=flags, shard=sh).cpu().numpy()
+            if accp.shape[0] != len(rows) or not np.array_equal(accp.view(np.uint32), acc[rows].view(np.uint32)):
+                wrong.append("accum")
+            if vm is not None and not np.array_equal(gp["nrdRadianceHitDist"].cpu().numpy().view(np.uint32), g["nrdRadianceHitDist"].cpu().numpy()[rows].view(np.uint32)):
+                wrong.append("nrdRadianceHitDist")
+            if wrong:
+                problems.append(("hybrid_shard", (count, index, strip), wrong))
         if vm is None:
             accr, _ = orc.hybrid(pc, cam, W, H, gnp, seed=seed, flags=flags)
         else:

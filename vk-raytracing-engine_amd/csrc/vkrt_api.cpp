@@ -872,6 +872,8 @@ int vkrt_gbuffer_raycast(vkrt_scene* s, const float clearColor[4], int lightsCou
 int vkrt_gbuffer_raycast_nrd(vkrt_scene* s, const float clearColor[4], int lightsCount, const GlobalUniforms* cam, const float viewMatrix[16],
                              const vkrt_shard* shard, const vkrt_gbuffer* out, const vkrt_nrd_planes* nrd, void* hip_stream)
 {
+  if(s && clearColor && cam && shard && out && nrd && vkrt_shard_rows(shard) == 0u)
+    return VKRT_OK;  // a shard without rows
   if(!nrd || !viewMatrix || !nrd->normalRoughness || !nrd->viewZ || !nrd->diffRadianceHitDist)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL NRD plane / view matrix");
   return gbufferImpl(s, clearColor, lightsCount, cam, viewMatrix, shard, out, nrd, hip_stream);
@@ -886,6 +888,8 @@ int vkrt_hybrid_trace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUnif
 int vkrt_hybrid_trace_nrd(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts, const vkrt_shard* shard,
                           const vkrt_gbuffer* g, const vkrt_nrd_planes* nrd, float* accum, void* hip_stream)
 {
+  if(s && pc && cam && shard && g && nrd && vkrt_shard_rows(shard) == 0u)
+    return VKRT_OK;  // a shard without rows
   if(!nrd || !nrd->viewZ || !nrd->diffRadianceHitDist)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL NRD plane");
   return hybridImpl(s, pc, cam, opts, shard, g, nrd, accum, hip_stream);
