@@ -145,6 +145,8 @@ def run_case(seed, verbose=False):
     if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SUBFRAMES] = int(rng.integers(1, 5))
     spp, depth, frames = int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(1, 3))
     L = int(rng.integers(1, len(flat.lights) + 1))
+    if rng.random() < 0.05:  # long sample sequences and deep paths (pixels far out of step with each other in the paired rounds)
+        spp, depth = int(rng.integers(4, 12)), int(rng.integers(7, 16))
     edge = rng.random()
     if edge < 0.02: spp = 0          # degenerate launches: the pixel is resolved without a ray
     elif edge < 0.04: depth = 0
