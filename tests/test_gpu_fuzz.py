@@ -22,3 +22,42 @@ def test_random_scenes_match_oracle():
             findings.append((info, problems))
     assert not findings, findings[:3]
     assert rays > 100000  # the cases do trace something
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [1, 0])
+def test_large_pile_of_coincident_triangles_builds_a_balanced_tree(layout):
+    """Found by the campaign: ~50 k triangles of which only a handful are distinct.  Every split of the SAH top builder ties; it used
+    to take the first one (1 : n - 1) and the clustered build ended in a chain ("BVH depth 153 needs a 158 KB LDS stack")."""
+    import numpy as np
+
+    import oracle_py
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, FlatScene
+    from vkrt_amd.renderer import Renderer
+
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-1, 1, (6, 3, 3)).astype(np.float32)  # six distinct triangles
+    n = 40000
+    pos = base[rng.integers(0, 6, n)].reshape(-1, 3)
+    V = pos.shape[0]
+    pm = np.zeros(1, PRIM_DTYPE); pm[0] = (0, V, 0, V, 0)
+    mats = np.zeros(1, MAT_DTYPE)
+    mats[0]["pbrBaseColorFactor"] = [0.8, 0.8, 0.8, 1.0]
+    mats[0]["pbrBaseColorTexture"] = mats[0]["metallicRoughnessTexture"] = mats[0]["normalTexture"] = mats[0]["emissiveTexture"] = -1
+    mats[0]["roughnessFactor"] = 1.0
+    nodes = np.zeros(1, NODE_DTYPE); nodes[0]["worldMatrix"] = np.eye(4, dtype=np.float32).ravel()
+    lights = np.zeros(1, LIGHT_DTYPE); lights[0] = ((0.3, 0.3, 3.0), (1, 1, 1), 10.0, 0)
+    flat = FlatScene(pos, np.tile(np.array([0, 0, 1], np.float32), (V, 1)), np.tile(np.array([1, 0, 0, 1], np.float32), (V, 1)),
+                     np.zeros((V, 2), np.float32), np.arange(V, dtype=np.uint32), pm, mats, lights, nodes, [])
+    for kind in ("ploc", "lbvh"):
+        r = Renderer(flat, device=0, build=kind, options={abi.VKRT_OPT_BVH_LAYOUT: layout})
+        c = r.check_accel()
+        assert c["triangles_referenced"] == n and c["triangles_missing"] == 0 and c["box_violations"] == 0 and c["bad_references"] == 0, c
+        assert c["max_depth"] <= 40, c
+        o = np.concatenate([rng.uniform(-1, 1, (2000, 2)), np.full((2000, 1), 4.0)], 1).astype(np.float32)
+        d = np.tile(np.array([[0, 0, -1]], np.float32), (2000, 1)) + rng.normal(0, 0.05, (2000, 3)).astype(np.float32)
+        t1, _, _, g1 = r.trace_rays(o, d)
+        r.close()
+        t0, _, _, g0, _ = oracle_py.OracleScene(flat).trace_rays(o, d, use_bvh=False)
+        assert np.array_equal(g0, g1) and np.array_equal(t0[g0 >= 0].view(np.uint32), t1[g0 >= 0].view(np.uint32))
