@@ -61,3 +61,33 @@ def test_large_pile_of_coincident_triangles_builds_a_balanced_tree(layout):
         r.close()
         t0, _, _, g0, _ = oracle_py.OracleScene(flat).trace_rays(o, d, use_bvh=False)
         assert np.array_equal(g0, g1) and np.array_equal(t0[g0 >= 0].view(np.uint32), t1[g0 >= 0].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_clustering_survives_passes_without_a_mutual_pair(monkeypatch):
+    """Found by the campaign: under rounding a clustering pass can end without any mutual pick ("PLOC pass without progress").  The
+    build then pairs neighbours in the next pass.  VKRT_PLOC_METRIC=98 makes EVERY search pass barren, so the tree is built by the
+    fallback alone: it must be sound and trace like the oracle."""
+    import os
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import atrium
+    import oracle_py
+    from vkrt_amd.renderer import Renderer
+
+    flat, _ = atrium.build_atrium(9000, seed=4, with_textures=False)
+    monkeypatch.setenv("VKRT_PLOC_METRIC", "98")
+    r = Renderer(flat, device=0, build="ploc")
+    monkeypatch.delenv("VKRT_PLOC_METRIC")
+    c = r.check_accel()
+    assert c["triangles_referenced"] == flat.instanced_triangle_count and c["triangles_missing"] == 0 and c["box_violations"] == 0 and c["bad_references"] == 0, c
+    rng = np.random.default_rng(2)
+    o = rng.uniform(-10, 10, (20000, 3)).astype(np.float32); o[:, 1] = np.abs(o[:, 1]) * 0.5 + 0.5
+    d = rng.normal(size=(20000, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t1, _, _, g1 = r.trace_rays(o, d.astype(np.float32))
+    r.close()
+    t0, _, _, g0, _ = oracle_py.OracleScene(flat).trace_rays(o, d.astype(np.float32))
+    assert np.array_equal(g0, g1) and (g0 >= 0).mean() > 0.5

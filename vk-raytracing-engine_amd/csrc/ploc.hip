@@ -71,11 +71,12 @@ VKRT_DEV float unionArea(const float* a, const float* b)  // a, b: lo[3] hi[3]
 // window without any mutual pair, and the loop must still shrink the array.
 __global__ __launch_bounds__(PLOC_BLOCK) void k_ploc_nn(int nc, int radius, int metric, const PlocCluster* __restrict__ c, int* __restrict__ nn)
 {
-  if(metric < 0)
+  if(metric < 0 || metric == 98)
   {
     const int i = (int)(blockIdx.x * PLOC_BLOCK + threadIdx.x);
     if(i < nc)
-      nn[i] = (i ^ 1) < nc ? (i ^ 1) : -1;
+      nn[i] = metric == 98 ? (i + 1 < nc ? i + 1 : -1)  // test hook (VKRT_PLOC_METRIC=98): picks that are never mutual
+                           : ((i ^ 1) < nc ? (i ^ 1) : -1);
     return;
   }
   __shared__ float box[(PLOC_BLOCK + 2 * PLOC_MAX_RADIUS) * 6];
