@@ -1,6 +1,6 @@
 """A slice of the randomised differential campaign (tools/fuzz_parity.py): random scenes, cameras, builders and options, the HIP
 path tracer and the hybrid passes against the CPU oracle, bit for bit.  The long runs are in profiles/r02_fuzz_parity.json
-(18 k cases, no findings); this keeps 120 fixed seeds in the driver's GPU pass."""
+(137 k cases; findings and fixes listed there); this keeps 120 fixed seeds in the driver's GPU pass."""
 import os
 import sys
 
