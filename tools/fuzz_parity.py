@@ -107,6 +107,11 @@ def random_scene(rng):
             M[:3, 3] = rng.uniform(-2, 2, 3)
         nd["worldMatrix"] = M.T.astype(np.float32).ravel()  # column-major storage
         nd["primMesh"] = int(rng.integers(0, n_mesh))
+    if rng.random() < 0.08:  # extreme instance scales (1e-3 .. 1e3, different per axis)
+        for nd in nodes:
+            M = np.asarray(nd["worldMatrix"], np.float64).reshape(4, 4).T
+            M[:3, :3] = M[:3, :3] @ np.diag(10.0 ** rng.uniform(-3, 3, 3))
+            nd["worldMatrix"] = M.T.astype(np.float32).ravel()
     if n_nodes > 1 and rng.random() < 0.1:  # the same instance twice: every triangle coincides with one of another gid (tie rule)
         nodes[1] = nodes[0]
     n_l = int(rng.integers(1, 5))
@@ -119,6 +124,27 @@ def random_scene(rng):
     return FlatScene(pos, nrm, tan, uv, idx, pm, mats, lights, nodes, textures)
 
 
+def needle_measure(flat):
+    """smallest height / longest-edge ratio over the instanced triangles (world space)"""
+    worst = 1.0
+    P = flat.positions.astype(np.float64)
+    for nd in flat.nodes:
+        M = np.asarray(nd["worldMatrix"], np.float64).reshape(4, 4).T
+        pm = flat.prim_meshes[int(nd["primMesh"])]
+        n = int(pm["indexCount"]) // 3
+        if n == 0:
+            continue
+        t = flat.indices[int(pm["firstIndex"]): int(pm["firstIndex"]) + 3 * n].reshape(n, 3).astype(np.int64) + int(pm["vertexOffset"])
+        W = P[t] @ M[:3, :3].T + M[:3, 3]
+        e1, e2 = W[:, 1] - W[:, 0], W[:, 2] - W[:, 0]
+        longest = np.maximum(np.maximum(np.linalg.norm(e1, axis=1), np.linalg.norm(e2, axis=1)), np.linalg.norm(e2 - e1, axis=1))
+        area2 = np.linalg.norm(np.cross(e1, e2), axis=1)
+        ok = longest > 0
+        if ok.any():
+            worst = min(worst, float((area2[ok] / longest[ok] ** 2).min()))
+    return worst
+
+
 def run_case(seed, verbose=False):
     rng = np.random.default_rng(seed)
     flat = random_scene(rng)
@@ -127,6 +153,8 @@ def run_case(seed, verbose=False):
         W, H = int(rng.integers(200, 330)), int(rng.integers(130, 210))
     eye = rng.uniform(-5, 5, 3); center = rng.uniform(-1, 1, 3)
     far = np.abs(flat.positions).max() > 100.0
+    if rng.random() < 0.05:  # a view from far away / from inside the geometry's bounding box
+        eye = center + rng.uniform(-1, 1, 3) * float(rng.choice([0.01, 300.0]))
     if far:  # look at the geometry wherever it is
         c0 = flat.positions.mean(0) if flat.nodes.shape[0] == 0 else np.asarray(flat.positions.mean(0), np.float64)
         center = c0 + rng.uniform(-1, 1, 3); eye = c0 + rng.uniform(-6, 6, 3)
@@ -177,7 +205,14 @@ def run_case(seed, verbose=False):
             same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
             info["oracle_tree_differs_from_brute_force"] = True
         if not same.all():
-            problems.append(("pathtrace", float(1 - same.all(-1).mean()), float(np.nanmax(np.abs(got - ref)))))
+            frac = float(1 - same.all(-1).mean())
+            if frac < 1e-3 and needle_measure(flat) < 1e-4:
+                # Needles (height below 1e-4 of the length, e.g. an instance flattened by a 1 : 1e5 scale): the triangle test accepts
+                # points far outside such a triangle, further than any box pad reaches, so whether the "hit" is found depends on
+                # the tree.  Known limit, not counted as a finding.
+                info["needle_limit_pixels"] = int((~same.all(-1)).sum())
+            else:
+                problems.append(("pathtrace", frac, float(np.nanmax(np.abs(got - ref)))))
         c = r.counters()
         info["rays"] = int(c["rays_closest"] + c["rays_shadow"])
         info["lit"] = float((np.nan_to_num(got[..., :3]).sum(-1) > 0).mean())
@@ -226,12 +261,21 @@ def run_case(seed, verbose=False):
             vm = np.linalg.inv(vi).T.astype(np.float32).ravel()
         g = r.gbuffer_raycast(cam, W, H, lights_count=max(L, 1), view_matrix=vm)
         gref = orc.gbuffer(cam, W, H, lights_count=max(L, 1)) if vm is None else orc.gbuffer_nrd(cam, vm, W, H, lights_count=max(L, 1))
-        for k in gref:
-            a, b = g[k].cpu().numpy(), gref[k]
-            diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
-            bad = diff.reshape(diff.shape[0], diff.shape[1], -1).any(-1).mean()
-            if bad > (0.02 if k.startswith("nrd") else 0.0):  # (the NRD planes are quantised: a boundary now and then; the G-buffer itself must be exact)
-                problems.append(("gbuffer_" + k, float(bad), float(np.nanmax(np.abs(a - b)))))
+        def gbuffer_findings(refplanes):
+            out = []
+            for k in refplanes:
+                a, b = g[k].cpu().numpy(), refplanes[k]
+                diff = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
+                bad = diff.reshape(diff.shape[0], diff.shape[1], -1).any(-1).mean()
+                if bad > (0.02 if k.startswith("nrd") else 0.0):  # (the NRD planes are quantised: a boundary now and then; the G-buffer itself must be exact)
+                    out.append(("gbuffer_" + k, float(bad), float(np.nanmax(np.abs(a - b)))))
+            return out
+        gf = gbuffer_findings(gref)
+        if gf:  # referee: the primary rays by the oracle's loop over all triangles
+            gref = orc.gbuffer(cam, W, H, lights_count=max(L, 1), use_bvh=False) if vm is None else orc.gbuffer_nrd(cam, vm, W, H, lights_count=max(L, 1), use_bvh=False)
+            gf = gbuffer_findings(gref)
+            info["oracle_tree_differs_from_brute_force"] = True
+        problems += gf
         pc = make_push_constants(samples=1, depth=max(depth, 2), frame=0, lights_count=max(L, 1))
         pc.useShadows, pc.useAO, pc.useGI = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
         gnp = {k: v.cpu().numpy() for k, v in g.items()}
@@ -287,7 +331,7 @@ def main():
     t0 = time.time()
     n = bad = 0
     failures = []
-    tris = rays = tree_notes = 0
+    tris = rays = tree_notes = needle_notes = 0
     lit = 0.0
     while time.time() - t0 < a.seconds:
         seed = a.seed * 1000003 + n
@@ -299,6 +343,7 @@ def main():
         n += 1
         tris += info.get("tris", 0)
         tree_notes += 1 if info.get("oracle_tree_differs_from_brute_force") else 0
+        needle_notes += 1 if info.get("needle_limit_pixels") else 0
         rays += info.get("rays", 0)
         lit += info.get("lit", 0.0)
         if problems:
@@ -307,7 +352,8 @@ def main():
         if n % 50 == 0:
             print(f"[{time.time() - t0:6.0f} s] {n} cases, {bad} with findings", flush=True)
     out = {"cases": n, "with_findings": bad, "seconds": round(time.time() - t0, 1), "triangles_total": tris, "rays_total": rays, "mean_lit_pixel_fraction": round(lit / max(n, 1), 3),
-           "cases_where_only_the_oracle_tree_walk_differed_from_brute_force": tree_notes, "first_seed": a.seed * 1000003, "failures": failures[:50]}
+           "cases_where_only_the_oracle_tree_walk_differed_from_brute_force": tree_notes,
+           "cases_at_the_needle_limit": needle_notes, "first_seed": a.seed * 1000003, "failures": failures[:50]}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1, default=str)
     print(json.dumps({k: v for k, v in out.items() if k != "failures"}))
