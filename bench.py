@@ -4,6 +4,8 @@ achieved HBM GB/s, Sponza 1080p 8-bounce).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no WORLD_SIZE in the environment: starts the N ranks itself, see self_launch)
+    python bench.py --gltf Sponza.gltf --eye X Y Z --center X Y Z [--fov F]   (a supplied scene file instead of the atrium)
 
 A "step" is one vkrt_pathtrace launch = one progressive frame of the workload: the seeded
 procedural Sponza-class atrium (tools/atrium.py; the real Sponza.gltf is not available offline),
@@ -18,17 +20,20 @@ Scene, BVH, working set and image are resident in HBM before the timed region.
 Mrays/s counts the closest-hit + shadow traceRay calls actually issued (device counters), summed over ranks.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  roofline     : dominant kernel k_wf_traverse.  achieved = the kernel's OWN algorithmic bytes per launch (80 B per
-                 8-wide node it visits + 48 B per triangle it tests + its ray / hit records; visit counts from an
-                 instrumented launch in this run) / its mean launch duration (HIP events on the launch stream, this run),
-                 against the 8 TB/s HBM3E peak.  Sub-blocks: `contract` (SURVEY 8d accounting on the oracle's BVH2 -- the
-                 figure the survey fixed before the data structure existed), `l2_gather` (same bytes against the
-                 measured L2 gather rate of MI355X_MICROARCH.md: the tree is L2-resident), `issue` (VALU wave-instructions
-                 against the issue rate calibrated by tools/issue_microbench.hip -> profiles/r02_issue_microbench.json;
-                 the resource that binds this kernel), `traffic` (fabric-side bytes from PMC passes).  PMC-derived numbers
-                 come from profiles/pmc_*.json and are used only when that file was measured on the same sources
-                 (vkrt_amd.source_hash) and workload; otherwise they are null.
-  cpu_baseline : the CPU oracle (scalar C++ restatement, kind "port") timed on a bounded row sample of the same frame.
+  roofline     : dominant kernel k_wf_traverse, priced against the resource that BINDS it: VALU issue.  achieved = VALU
+                 wave-instructions per launch (SQ_INSTS_VALU per ray from the committed PMC pass x rays per launch of this
+                 run) / the kernel's mean launch duration (HIP events on the launch stream, this run); peak = the full-rate
+                 issue peak calibrated by tools/issue_microbench.hip (profiles/r02_issue_microbench.json); `frac_nominal`
+                 prices the same rate against the nominal 256 CU x 4 SIMD x 2.4 GHz / 2 cycles = 1228.8 G wave-instr/s.
+                 Sub-blocks, none of them a bound for this kernel: `hbm_own_bytes` (the kernel's own algorithmic bytes --
+                 80 B per 8-wide node visited + 48 B per triangle tested + ray / hit records, visit counts from an
+                 instrumented launch of this run -- against the 8 TB/s HBM3E peak), `contract` (SURVEY 8d accounting on the
+                 oracle's BVH2; exceeds 1), `l2_gather` (own bytes against the guide's measured L2 gather rate: the tree is
+                 L2-resident), `traffic` / `traffic_detail` (fabric-side HBM bytes per launch from separate PMC passes).
+                 PMC-derived numbers come from profiles/pmc_*.json; they are tied to the kernel sources by
+                 vkrt_amd.source_hash and flagged `pmc_stale` when that file was measured on other sources.
+  cpu_baseline : the CPU oracle (scalar C++ restatement, kind "port") timed on a bounded row sample of the same frame, on all
+                 host threads (`value`) and on one thread (`single_thread`), with the host's CPU model string.
 """
 import argparse
 import json
@@ -46,6 +51,65 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, HBM)
 L2_GATHER_GBS = 16800.0   # same guide, "Indexed rows": rows shared by every workgroup, served by the XCDs' L2 (16.8-18.8 TB/s)
+ISSUE_NOMINAL_G = 256 * 4 * 2.4 / 2.0  # 1228.8 G wave64 VALU instructions/s: 256 CUs x 4 SIMDs x 2.4 GHz, 2 cycles per full-rate instruction
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (one process per GPU, the same
+    torch.distributed.run command the driver would use) BEFORE this process touches the GPU, relay rank 0's JSON line and
+    return the launcher's exit code.  (Never re-exec: a process that has initialised the GPU must not be replaced.)"""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] no WORLD_SIZE in the environment: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:  # rank 0's line (and nothing else) goes to our stdout
+        if line.lstrip().startswith("{"):
+            print(line, end="", flush=True)
+        else:
+            print(line, end="", file=sys.stderr, flush=True)
+    return p.wait()
+
+
+def launch_selftest(args):
+    """--launch-selftest: the control flow of an N-rank run without a GPU (gloo): rendezvous, one all_reduce, rank 0's line."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_selftest": True, "n_gpus": world, "gpus_arg": args.gpus, "rank_sum": float(t.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def image_size(n_gpus, base_w, base_h):
@@ -60,7 +124,10 @@ def image_size(n_gpus, base_w, base_h):
 
 
 def workload_key(args, W, H, triangles):
-    return f"atrium{triangles}_{W}x{H}_{args.spp}spp_d{args.depth}_{'tex' if not args.no_textures else 'notex'}_{args.build}"
+    scene = f"atrium{triangles}" if not args.gltf else f"gltf-{os.path.basename(args.gltf)}-{triangles}"
+    if not args.gltf and args.variant != "default":
+        scene += "-" + args.variant
+    return f"{scene}_{W}x{H}_{args.spp}spp_d{args.depth}_{'tex' if not args.no_textures else 'notex'}_{args.build}"
 
 
 def fresh_profile(path, key):
@@ -95,7 +162,19 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: N x 1080p pixels instead of one fixed 3840x2160 frame")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo for rehearsals")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="all ranks use cuda:0 (control-flow rehearsal on a 1-GPU box; needs --backend gloo)")
+    ap.add_argument("--variant", default="default", help="atrium variant (tools/atrium.py), e.g. nonuniform = wall-sized triangles next to millimetre trim and drapery")
+    ap.add_argument("--gltf", default=None, help="render this .gltf / .glb through the product's C++ loader instead of the procedural atrium "
+                                                 "(e.g. the Khronos Sponza the reference's config.json names)")
+    ap.add_argument("--eye", type=float, nargs=3, default=None, help="camera position (with --gltf; default: the reference's (0, 0, 15))")
+    ap.add_argument("--center", type=float, nargs=3, default=None, help="look-at point (default: the origin)")
+    ap.add_argument("--up", type=float, nargs=3, default=None)
+    ap.add_argument("--fov", type=float, default=None, help="vertical field of view in degrees (default 60)")
+    ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launch_selftest:
+        sys.exit(launch_selftest(args))
 
     import numpy as np
     import torch
@@ -112,8 +191,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     if args.rehearse_on_one_gpu:
@@ -137,8 +214,22 @@ def main():
     else:
         W, H = (3840, 2160) if world > 1 else (1920, 1080)
         scaling = "strong" if world > 1 else "weak"  # N = 1: one GPU, nothing to scale; kept "weak" as the contract's default
-    flat, info = atrium.build_atrium(args.triangles, seed=args.scene_seed, with_textures=not args.no_textures)
-    cam = host_py.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA)  # the product's camera (host/camera.h)
+    if args.gltf:
+        # a supplied scene file (the reference's config.json scenes: Sponza, suntemple, ... -- git-ignored upstream): the product's
+        # C++ loader flattens it exactly as for vkrt_render; camera from the command line, defaults = the reference's start-up camera
+        flat = host_py.load_gltf(args.gltf)
+        info = {"triangles": int(flat.instanced_triangle_count), "seed": None}
+        camkw = {k: tuple(v) for k, v in (("eye", args.eye), ("center", args.center), ("up", args.up)) if v is not None}
+        if args.fov is not None:
+            camkw["fov"] = args.fov
+        scene_text = f"{os.path.basename(args.gltf)} ({info['triangles']} instanced tris, {len(flat.textures)} textures)"
+    else:
+        kw = {} if args.variant == "default" else {"variant": args.variant}
+        flat, info = atrium.build_atrium(args.triangles, seed=args.scene_seed, with_textures=not args.no_textures, **kw)
+        camkw = dict(atrium.DEFAULT_CAMERA)
+        scene_text = (f"procedural Sponza-class atrium ({info['triangles']} tris, seed {info['seed']}, "
+                      f"{'textured' if not args.no_textures else 'untextured'}{'' if args.variant == 'default' else ', variant ' + args.variant})")
+    cam = host_py.global_uniforms(width=W, height=H, **camkw)  # the product's camera (host/camera.h)
     lights = int(flat.lights.shape[0])
 
     # ---- scene upload + acceleration structure (timed apart from the trace) ----------------------------------
@@ -243,9 +334,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"procedural Sponza-class atrium ({info['triangles']} tris, seed {info['seed']}, "
-                            f"{'textured' if not args.no_textures else 'untextured'}) {W}x{H}, {args.spp} spp/frame, depth {args.depth}, "
-                            f"{lights} fallback lights, progressive frames"
+                "workload": f"{scene_text} {W}x{H}, {args.spp} spp/frame, depth {args.depth}, "
+                            f"{lights} lights, progressive frames"
                             + (f" = BASELINE config 4 frame sharded over {world} GPUs" if world > 1 and (W, H) == (3840, 2160) else ""),
                 "width": W, "height": H, "spp": args.spp, "depth": args.depth, "triangles": info["triangles"],
                 "bvh": args.build, "bvh_nodes": accel["node_count"], "bvh_depth": accel["max_depth"],
@@ -265,44 +355,64 @@ def main():
             # hit record out (1 float4 + the 16-B shading record of closest hits)
             node_b = 80 if accel["node_bytes"] and accel["node_bytes"] // max(accel["node_count"], 1) >= 80 else 64
             own = (node_b * work["nodes_visited"] + 48 * work["tris_tested"] + 32 * rays_frame + 16 * rays_frame + 16 * work["hits"]) / n_l
-            achieved = own / (per_launch_ms * 1e-3) / 1e9
-            roof = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            own_gbs = own / (per_launch_ms * 1e-3) / 1e9
+            common = {
                 "kernel": "k_wf_traverse", "kernel_ms": per_launch_ms, "launches_per_frame": n_l, "rays_per_launch": rays_launch,
-                "algorithmic_bytes_per_launch": own, "algorithmic_bytes_per_ray": own / rays_launch,
                 "per_ray": {"nodes_visited": work["nodes_visited"] / rays_frame, "tris_tested": work["tris_tested"] / rays_frame,
                             "node_step_lane_efficiency": work["nodes_visited"] / max(64 * work["wave_node_steps"], 1),
                             "tri_step_lane_efficiency": work["tris_tested"] / max(64 * work["wave_tri_steps"], 1)},
-                "binding": "valu-issue",
-                "l2_gather": {"achieved": achieved, "peak": L2_GATHER_GBS, "unit": "GB/s", "frac": achieved / L2_GATHER_GBS,
-                              "note": "the 3.4-MB node array and most of the 12.6-MB triangle array are served by the XCDs' L2s: same bytes against the "
-                                      "guide's measured L2 gather rate"},
                 "frame": {"ms": float(np.mean(frame_ms)), "traverse_ms": float(np.mean(trav_ms))},
+                # sub-blocks: other ways of pricing the same launch; none of them bounds this kernel
+                "hbm_own_bytes": {"achieved": own_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": own_gbs / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_launch": own, "algorithmic_bytes_per_ray": own / rays_launch,
+                                  "note": "NOT a bound: what the kernel's algorithm fetches from its own data structure (80 B per 8-wide node visited + 48 B "
+                                          "per triangle tested + ray / hit records, counted by the kernel) against the HBM peak; the tree is cache-resident, so "
+                                          "these bytes come from L2 / Infinity Cache (see traffic)"},
+                "l2_gather": {"achieved": own_gbs, "peak": L2_GATHER_GBS, "unit": "GB/s", "frac": own_gbs / L2_GATHER_GBS,
+                              "note": "NOT a bound: the node array and most of the triangle array are served by the XCDs' L2s: own bytes against the "
+                                      "guide's measured L2 gather rate"},
                 "note": "kernel_ms = mean duration of un-overlapped k_wf_traverse launches (timing pass, one sub-frame); value is measured with the "
-                        "default three-sub-frame pipeline.  Bytes are what the kernel's algorithm fetches from its own data structure, counted by the "
-                        "kernel; they are served from L2 / Infinity Cache (traffic), so HBM does not bind -- VALU issue does (issue).",
+                        "default three-sub-frame pipeline.  The kernel is bound by VALU issue (about half of its instructions are half-rate opcodes, so "
+                        "its mix-adjusted ceiling is ~0.65 of the full-rate peak); HBM moves 0.3x the algorithmic bytes (traffic).",
             }
-            pm = fresh_profile(os.path.join(ROOT, "profiles", "pmc_traffic.json"), key)
-            if pm:
-                roof["traffic"] = pm["hbm_bytes_per_ray"] * rays_launch
-                roof["traffic_detail"] = {"read_bytes_per_ray_raw": pm["read_bytes_per_ray_raw"], "write_bytes_per_ray": pm["write_bytes_per_ray"],
-                                          "source": "profiles/pmc_traffic.json (reads x2 per the guide's gfx950 note)"}
+            # the binding resource: VALU issue.  Instructions per ray come from a separate --pmc SQ_INSTS_VALU pass (profiles/pmc_issue.json)
+            roof = None
             try:
                 mb = json.load(open(os.path.join(ROOT, "profiles", "r02_issue_microbench.json")))
                 peak = max(v["8"]["G_wave_instr_per_s"] for k, v in mb.items() if k in ("v_fma_f32", "v_mul_f32", "v_add_f32"))
                 half = float(np.mean([mb[k]["8"]["G_wave_instr_per_s"] for k in ("v_cvt_f32_ubyte0", "v_max3_f32", "v_min3_f32", "v_cmp_lt_f32")]))
-                issue = {"bound": "valu-issue", "peak": peak, "unit": "G wave-instr/s", "achieved": None, "frac": None,
-                         "peak_source": "profiles/r02_issue_microbench.json: best full-rate opcode class at 8 waves/SIMD (v_fma/v_mul/v_add, 2 cycles per wave64 "
-                                        f"instruction per SIMD); v_cvt_f32_ubyte*, v_min/max(3)_f32, v_cmp, VOP3 integer ops issue at half that rate ({half:.0f} G/s)"}
-                pi = fresh_profile(os.path.join(ROOT, "profiles", "pmc_issue.json"), key)
-                if pi:
-                    instr = pi["valu_wave_instr_per_ray"] * rays_launch
-                    got = instr / (per_launch_ms * 1e-3) / 1e9
-                    issue.update({"achieved": got, "frac": got / peak, "valu_wave_instr_per_launch": instr, "valu_wave_instr_per_ray": pi["valu_wave_instr_per_ray"],
-                                  "source": "profiles/pmc_issue.json (SQ_INSTS_VALU per ray, same sources and workload) x rays per launch of this run"})
-                roof["issue"] = issue
+                pi, stale = fresh_profile(os.path.join(ROOT, "profiles", "pmc_issue.json"), key), False
+                if pi is None:  # measured on other sources or another workload: still the best figure there is -- used, and flagged
+                    pi, stale = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json"))), True
+                instr = pi["valu_wave_instr_per_ray"] * rays_launch
+                got = instr / (per_launch_ms * 1e-3) / 1e9
+                roof = {"bound": "valu-issue", "achieved": got, "peak": peak, "unit": "G wave-instr/s", "frac": got / peak,
+                        "peak_nominal": ISSUE_NOMINAL_G, "frac_nominal": got / ISSUE_NOMINAL_G, "traffic": None,
+                        "valu_wave_instr_per_launch": instr, "valu_wave_instr_per_ray": pi["valu_wave_instr_per_ray"], "pmc_stale": stale,
+                        "source": "profiles/pmc_issue.json (SQ_INSTS_VALU per ray" + (", measured on OTHER sources / workload: " + str(pi.get("workload"))
+                                  if stale else ", same sources and workload") + ") x rays per launch of this run",
+                        "peak_source": "profiles/r02_issue_microbench.json: best full-rate opcode class at 8 waves/SIMD (v_fma/v_mul/v_add, 2 cycles per wave64 "
+                                       f"instruction per SIMD, clock-throttled); v_cvt_f32_ubyte*, v_min/max(3)_f32, v_cmp, VOP3 integer ops issue at half that rate "
+                                       f"({half:.0f} G/s); peak_nominal = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles"}
             except Exception:
-                pass
+                roof = None
+            if roof is None:  # no issue profile at all: fall back to the byte view, labelled as what it is
+                roof = {"bound": "hbm", "achieved": own_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": own_gbs / HBM_PEAK_GBS, "traffic": None,
+                        "fallback": "no VALU-issue profile (profiles/pmc_issue.json) available: own algorithmic bytes against the HBM peak; not a bound"}
+            roof.update(common)
+            pm, tstale = fresh_profile(os.path.join(ROOT, "profiles", "pmc_traffic.json"), key), False
+            if pm is None:
+                try:
+                    pm, tstale = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))), True
+                except Exception:
+                    pm = None
+            if pm:
+                roof["traffic"] = pm["hbm_bytes_per_ray"] * rays_launch
+                tg = roof["traffic"] / (per_launch_ms * 1e-3) / 1e9
+                roof["traffic_detail"] = {"read_bytes_per_ray_raw": pm["read_bytes_per_ray_raw"], "write_bytes_per_ray": pm["write_bytes_per_ray"],
+                                          "achieved": tg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tg / HBM_PEAK_GBS, "pmc_stale": tstale,
+                                          "over_algorithmic_bytes": roof["traffic"] / own,
+                                          "source": "profiles/pmc_traffic.json (FETCH_SIZE / WRITE_SIZE passes, reads x2 per the guide's gfx950 note)"}
             out["roofline"] = roof
         elif frame_ms:
             own = (64 * work["nodes_visited"] + 48 * work["tris_tested"]) if work["nodes_visited"] else 0
@@ -330,26 +440,37 @@ def main():
             frame = args.warmup  # the first timed frame
             pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
             threads = min(16, os.cpu_count() or 1)  # the 1-GPU box grants 16 CPUs
-            probe_rows = np.linspace(0, H - 1, 4).astype(np.uint32)
-            buf = np.zeros((len(probe_rows), W, 4), np.float32)
-            tp = time.perf_counter()
-            orc.render(pc, cam, W, H, seed=frame, rows=probe_rows, image=buf, threads=threads)
-            per_row = (time.perf_counter() - tp) / len(probe_rows)
-            nrows = int(max(threads, min(H, args.cpu_seconds / max(per_row, 1e-6))))
-            for attempt in range(2):  # the probe's first rows run cold and overestimate the row time: rescale once if the sample fell short
-                rows = np.unique(np.linspace(0, H - 1, nrows).astype(np.uint32))
-                buf = np.zeros((len(rows), W, 4), np.float32)
+
+            def sample(nthreads, seconds):
+                """rows of the frame rendered by the oracle for about `seconds` of wall time on `nthreads` threads"""
+                probe_rows = np.linspace(0, H - 1, max(2, min(4, nthreads))).astype(np.uint32)
+                buf = np.zeros((len(probe_rows), W, 4), np.float32)
                 tp = time.perf_counter()
-                _, c = orc.render(pc, cam, W, H, seed=frame, rows=rows, image=buf, threads=threads)
-                cpu_s = time.perf_counter() - tp
-                if cpu_s >= 0.6 * args.cpu_seconds or len(rows) >= H:
-                    break
-                nrows = int(min(H, len(rows) * args.cpu_seconds / max(cpu_s, 1e-6)))
+                orc.render(pc, cam, W, H, seed=frame, rows=probe_rows, image=buf, threads=nthreads)
+                per_row = (time.perf_counter() - tp) / len(probe_rows)
+                nrows = int(max(nthreads, min(H, seconds / max(per_row, 1e-6))))
+                for attempt in range(2):  # the probe's first rows run cold and overestimate the row time: rescale once if the sample fell short
+                    rows = np.unique(np.linspace(0, H - 1, nrows).astype(np.uint32))
+                    buf = np.zeros((len(rows), W, 4), np.float32)
+                    tp = time.perf_counter()
+                    _, c = orc.render(pc, cam, W, H, seed=frame, rows=rows, image=buf, threads=nthreads)
+                    cpu_s = time.perf_counter() - tp
+                    if cpu_s >= 0.6 * seconds or len(rows) >= H:
+                        break
+                    nrows = int(min(H, len(rows) * seconds / max(cpu_s, 1e-6)))
+                return rows, c, cpu_s
+
+            rows, c, cpu_s = sample(threads, args.cpu_seconds)
+            rows1, c1, cpu_s1 = sample(1, 0.6 * args.cpu_seconds)
             cpu_rays = c["rays_closest"] + c["rays_shadow"]
+            cpu_rays1 = c1["rays_closest"] + c1["rays_shadow"]
             out["cpu_baseline"] = {
                 "value": cpu_rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": f"{len(rows)} evenly spaced rows of frame {frame} of the same {W}x{H} workload ({cpu_rays} rays, {cpu_s:.1f} s), "
                           f"full-sweep SAH BVH2 <=4 tris/leaf",
+                "single_thread": {"value": cpu_rays1 / cpu_s1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                                  "sample": f"{len(rows1)} rows ({cpu_rays1} rays, {cpu_s1:.1f} s)"},
+                "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
             }
             if "roofline" in out and out["roofline"].get("kernel") == "k_wf_traverse":
                 tb = (64 * c["nodes_visited"] + 48 * c["tris_tested"]) / cpu_rays
@@ -357,8 +478,8 @@ def main():
                 cg = tb * rl["rays_per_launch"] / (rl["kernel_ms"] * 1e-3) / 1e9
                 rl["contract"] = {"bytes_per_ray_traversal": tb, "bytes_per_ray_all": oracle_py.algorithmic_bytes(c, frame_gt0=frame > 0) / cpu_rays,
                                   "achieved": cg, "peak": HBM_PEAK_GBS, "frac": cg / HBM_PEAK_GBS,
-                                  "note": "SURVEY 8d accounting: 64 B per node visit + 48 B per triangle test of the ORACLE's binary tree on the same rays. "
-                                          "Not the kernel's data structure (an 8-wide compressed tree needs ~0.6x the bytes), so this fraction can exceed 1"}
+                                  "note": "NOT a bound: SURVEY 8d accounting, 64 B per node visit + 48 B per triangle test of the ORACLE's binary tree on the same "
+                                          "rays.  Not the kernel's data structure (an 8-wide compressed tree needs ~0.6x the bytes), so this fraction exceeds 1"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

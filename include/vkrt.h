@@ -271,7 +271,15 @@ int vkrt_hybrid_trace_nrd(vkrt_scene* scene, const PushConstantRay* pc, const Gl
                           const vkrt_shard* shard, const vkrt_gbuffer* gbuffer, const vkrt_nrd_planes* nrd, float* accum_rgba32f_device,
                           void* hip_stream);
 /* Replaces drawPost's fragment stage (post.frag:36-58): hybrid composite main.rgb * rt.a + rt.rgb (rtMode 0) or
- * pass-through (rtMode 1), then gamma 1/2.2 on all four channels.  n_pixels rgba32f device buffers. */
+ * pass-through (rtMode 1), then gamma 1/2.2 on all four channels.  n_pixels rgba32f device buffers.
+ * NaN texels are part of the result, as in the reference: post.frag:57 applies pow(x, 1/2.2) to whatever the composite holds
+ * and pow of a negative base is undefined in GLSL (NaN here, on the oracle and on the GPUs the reference targets).  The
+ * hybrid accumulation plane does go negative -- raytrace.rchit's specular branch returns negative weights when
+ * dot(N, L) < 0 and raytraceHybrid.rgen adds the GI radiance unclamped -- so a hybrid frame shows them:
+ * 898 of the 46,080 texels sampled by the BASELINE config-5 test (1920x1080 atrium, shadows + AO + GI depth 8, two frames),
+ * at the same texels on both sides (tests/test_gpu_configs.py asserts the coincidence).  The path-tracing mode's image
+ * (rtMode 1) is not affected in practice: raytrace.rgen clamps every contribution with min(., 10) but sums can still be
+ * negative; callers that display the plane should treat NaN as black, like a UNORM swapchain write does. */
 int vkrt_post(int device, const PushConstantPost* pc, uint32_t n_pixels, const float* main_rgba32f, const float* rt_rgba32f,
               float* out_rgba32f, void* hip_stream);
 

@@ -375,8 +375,21 @@ inline void consider(const Tri& tr, V3 o, V3 d, float tmin, Hit& best, Counters&
   }
 }
 
+// Optional tap (debug / parity localisation): every ray handed to the four queries below is appended as 9 floats
+// {o.xyz, d.xyz, tmin, tmax, any ? 1 : 0} while a thread has set it (orc_hybrid_pixel_rays).
+thread_local std::vector<float>* g_rayTap = nullptr;
+inline void tapRay(V3 o, V3 d, float tmin, float tmax, bool any)
+{
+  if(g_rayTap)
+  {
+    const float r[9] = {o.x, o.y, o.z, d.x, d.y, d.z, tmin, tmax, any ? 1.0f : 0.0f};
+    g_rayTap->insert(g_rayTap->end(), r, r + 9);
+  }
+}
+
 Hit closest_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
 {
+  tapRay(o, d, tmin, tmax, false);
   Hit best{tmax, 0, 0, -1};
   // tmax exclusive: a hit needs t < tmax; emulate by starting best.t = tmax with tri = -1
   // (tie rule "gid < -1" never holds, so t == tmax is rejected).
@@ -386,6 +399,7 @@ Hit closest_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counte
 }
 bool any_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
 {
+  tapRay(o, d, tmin, tmax, true);
   for(const Tri& tr : s.tris)
   {
     float t, u, v;
@@ -398,6 +412,7 @@ bool any_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters&
 
 Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
 {
+  tapRay(o, d, tmin, tmax, false);
   Hit best{tmax, 0, 0, -1};
   if(s.tris.empty())
     return best;
@@ -438,6 +453,7 @@ Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters
 }
 bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
 {
+  tapRay(o, d, tmin, tmax, true);
   if(s.tris.empty())
     return false;
   RayInv r{o, v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z))};
@@ -1904,6 +1920,22 @@ int orc_hybrid_rows_nrd(const orc_scene* s, const PushConstantRay* pc, const Glo
       hybridPixel(*s, *pc, *cam, seed, flags, x, rows[r], full_w, use_bvh != 0, g, accum + 4 * p, c, radHitD + 4 * p);
     }
   return 0;
+}
+
+/* The rays raytraceHybrid.rgen traces for ONE pixel, in order (9 floats each: o.xyz, d.xyz, tmin, tmax, any-hit flag); gpix = the
+ * pixel's G-buffer texels (color4, position4, normal4, rough2).  Returns the number of floats the full log has. */
+int orc_hybrid_pixel_rays(const orc_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, uint32_t seed, uint32_t flags, uint32_t full_w,
+                          uint32_t x, uint32_t y, const float* gpix, int use_bvh, float* accum4, float* rays, int cap)
+{
+  GbufPixel g;
+  memcpy(g.color, gpix, 16); memcpy(g.position, gpix + 4, 16); memcpy(g.normal, gpix + 8, 16); memcpy(g.rough, gpix + 12, 8);
+  std::vector<float> v;
+  Counters c;
+  g_rayTap = &v;
+  hybridPixel(*s, *pc, *cam, seed, flags, x, y, full_w, use_bvh != 0, g, accum4, c);
+  g_rayTap = nullptr;
+  memcpy(rays, v.data(), sizeof(float) * std::min<size_t>(v.size(), (size_t)cap));
+  return (int)v.size();
 }
 
 /* raytraceHybrid.rgen over rows[0..nrows) given the G-buffer planes of those rows; accum (nrows x W x 4) is in/out. */

@@ -56,6 +56,9 @@ def lib():
         L.orc_hybrid_rows.argtypes = [C.c_void_p, P(abi.PushConstantRay), P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_hybrid_rows.restype = C.c_int
+        L.orc_hybrid_pixel_rays.argtypes = [C.c_void_p, P(abi.PushConstantRay), P(abi.GlobalUniforms), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_hybrid_pixel_rays.restype = C.c_int
         L.orc_gbuffer_rows_nrd.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(abi.GlobalUniforms), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_gbuffer_rows_nrd.restype = C.c_int
@@ -169,6 +172,16 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("orc_hybrid_rows: " + lib().orc_last_error().decode())
         return accum, dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
+
+    def hybrid_pixel_rays(self, pc, cam, width, x, y, g, seed=0, flags=0, use_bvh=False):
+        """The rays raytraceHybrid.rgen traces for pixel (x, y), in order: (accum texel, array [n, 9] = o, d, tmin, tmax, any flag).
+        g: G-buffer planes of the whole frame (numpy)."""
+        gp = np.concatenate([g["color"][y, x], g["position"][y, x], g["normal"][y, x], g["roughMetal"][y, x]]).astype(np.float32)
+        acc = np.zeros(4, np.float32)
+        rays = np.zeros(9 * 4096, np.float32)
+        n = lib().orc_hybrid_pixel_rays(self._h, C.byref(pc), C.byref(cam), seed, flags, width, x, y, gp.ctypes.data, 1 if use_bvh else 0,
+                                        acc.ctypes.data, rays.ctypes.data, rays.shape[0])
+        return acc, rays[: min(n, rays.shape[0])].reshape(-1, 9)
 
     def gbuffer_nrd(self, cam, view_matrix, width, height, lights_count, clear_color=(1.0, 1.0, 1.0, 1.0), rows=None, use_bvh=True):
         """gbuffer() plus the NRD front-end planes of the raster pass (frag_shader.frag:133-136)."""

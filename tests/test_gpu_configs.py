@@ -36,16 +36,39 @@ def mismatch_fraction(a, b):
     return float(np.mean(np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1)))
 
 
+class MemoOracle:
+    """The oracle's answers do not depend on the GPU builder under test: rendered once per (call, arguments), reused by the
+    other builder's run of the same test (copies, because progressive frames update images in place)."""
+
+    def __init__(self, orc):
+        self.orc, self.memo = orc, {}
+
+    def call(self, key, fn):
+        import copy
+
+        if key not in self.memo:
+            self.memo[key] = fn(self.orc)
+        return copy.deepcopy(self.memo[key])
+
+
 @pytest.fixture(scope="module")
-def atrium_full():
-    """The bench workload's scene (262,144 instanced triangles, textured, 8 fallback lights) with its oracle and renderer."""
+def atrium_scene():
     import atrium
     import oracle_py
-    from vkrt_amd.renderer import Renderer
 
     flat, info = atrium.build_atrium(262144, seed=1, with_textures=True)
-    r = Renderer(flat, device=0, build="sah")
-    yield flat, oracle_py.OracleScene(flat), r, atrium.DEFAULT_CAMERA
+    return flat, MemoOracle(oracle_py.OracleScene(flat)), atrium.DEFAULT_CAMERA
+
+
+@pytest.fixture(scope="module", params=["ploc", "sah"])
+def atrium_full(request, atrium_scene):
+    """The bench workload's scene (262,144 instanced triangles, textured, 8 fallback lights) with its oracle and a renderer on
+    the tree of each builder: "ploc" = the default, device-built tree that bench.py measures; "sah" = the host build."""
+    from vkrt_amd.renderer import Renderer
+
+    flat, memo, camkw = atrium_scene
+    r = Renderer(flat, device=0, build=request.param)
+    yield flat, memo, r, camkw
     r.close()
 
 
@@ -108,7 +131,7 @@ def test_config4_4k_shard_of_8_rows_match_oracle(atrium_full, rank):
     c = r.counters()
     assert part.shape == (len(grow), W, 4)
     pick = np.unique(np.linspace(0, len(grow) - 1, 10).astype(np.int64))
-    ref, cref = orc.render(pc, cam, W, H, seed=0, rows=grow[pick].astype(np.uint32), threads=THREADS)
+    ref, cref = orc.call(("c4", rank), lambda o: o.render(pc, cam, W, H, seed=0, rows=grow[pick].astype(np.uint32), threads=THREADS))
     assert rmse(part[pick], ref) < RMSE_TOL
     assert mismatch_fraction(part[pick], ref) < 1e-4
     assert c["pixels"] == len(grow) * W
@@ -134,7 +157,7 @@ def test_config4_4k_eight_shards_reassemble_to_the_unsharded_image(atrium_full):
         out[shard_row_indices(H, 8, rank)] = r.pathtrace(pc, cam, W, H, seed=4, shard=make_shard(W, H, 8, rank)).cpu().numpy()
     assert hashlib.sha256(out.tobytes()).hexdigest() == want
     rows = np.array([7, 1080, 2159], np.uint32)
-    ref, _ = orc.render(pc, cam, W, H, seed=4, rows=rows, threads=THREADS)
+    ref, _ = orc.call("c4-whole", lambda o: o.render(pc, cam, W, H, seed=4, rows=rows, threads=THREADS))
     assert mismatch_fraction(full[rows], ref) < 1e-4 and rmse(full[rows], ref) < RMSE_TOL
 
 
@@ -151,7 +174,7 @@ def test_config5_hybrid_1080p_full_atrium(atrium_full):
     cam = default_camera(W, H, **camkw)
     rows = np.unique(np.linspace(0, H - 1, 20).astype(np.uint32))
     g = r.gbuffer_raycast(cam, W, H, lights_count=lights)
-    go = orc.gbuffer(cam, W, H, lights_count=lights, rows=rows, threads=THREADS)
+    go = orc.call("c5-gbuffer", lambda o: o.gbuffer(cam, W, H, lights_count=lights, rows=rows, threads=THREADS))
     for k in go:
         assert mismatch_fraction(g[k].cpu().numpy()[rows], go[k]) < 1e-3, k
     assert rmse(g["color"].cpu().numpy()[rows], go["color"]) < RMSE_TOL
@@ -160,13 +183,19 @@ def test_config5_hybrid_1080p_full_atrium(atrium_full):
         pc = make_push_constants(samples=1, depth=8, frame=f, lights_count=lights)
         pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
         acc = r.hybrid_trace(pc, cam, W, H, g, seed=3 + f, accum=acc)
-        ao, _ = orc.hybrid(pc, cam, W, H, go, seed=3 + f, rows=rows, accum=ao, threads=THREADS)
+        ao = orc.call(("c5-hybrid", f), lambda o: o.hybrid(pc, cam, W, H, go, seed=3 + f, rows=rows, accum=ao, threads=THREADS)[0])
     got = acc.cpu().numpy()[rows]
     assert rmse(got, ao) < RMSE_TOL
     assert mismatch_fraction(got, ao) < 1e-3
     disp = r.post(g["color"], acc, rt_mode=0, use_gi=1).cpu().numpy()[rows]
     want = oracle_py.post(go["color"], ao, rt_mode=0, use_gi=1)
-    ok = ~(np.isnan(disp) | np.isnan(want))
+    # post.frag:57 is pow(color, 1/2.2) on whatever the composite holds, and raytrace.rchit's specular weights can be negative
+    # (SURVEY Appendix A), so a hybrid frame's display plane carries NaN texels -- about 2 % of this frame, documented next to
+    # vkrt_post in include/vkrt.h.  They are part of the result: both sides must have them at the same texels.
+    nan_g, nan_o = np.isnan(disp), np.isnan(want)
+    assert np.mean(nan_g ^ nan_o) < 1e-4, (int(nan_g.sum()), int(nan_o.sum()))
+    assert 0 < nan_o.any(-1).mean() < 0.05
+    ok = ~(nan_g | nan_o)
     assert np.abs(np.where(ok, disp - want, 0.0)).max() < 2e-5  # pow() is outside the bit-exact profile
 
 

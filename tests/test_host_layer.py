@@ -249,6 +249,30 @@ def test_end_to_end_cpp_host_render_matches_oracle(tmp_path, small_atrium):
 
 
 @pytest.mark.gpu
+def test_bench_runs_a_supplied_gltf(tmp_path, small_atrium):
+    """"if the user drops the real Khronos Sponza next to the config, the same harness runs it" (config.json:2-7).
+    bench.py --gltf on an exported scene file: one JSON line with the contract's fields, rays counted, roofline present."""
+    import subprocess
+
+    import atrium
+    import gltf_export
+
+    path = str(tmp_path / "supplied.gltf")
+    gltf_export.export_gltf(small_atrium, path)
+    cam = atrium.DEFAULT_CAMERA
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gltf", path, "--width", "320", "--height", "180", "--spp", "2", "--depth", "4", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-other-builder", "--eye", *map(str, cam["eye"]), "--center", *map(str, cam["center"]), "--fov", str(cam.get("fov", 60.0))]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "Mrays/s" and d["value"] > 0 and d["n_gpus"] == 1 and "supplied.gltf" in d["config"]["workload"]
+    assert d["config"]["triangles"] == small_atrium.instanced_triangle_count and d["config"]["rays_per_step"] > 320 * 180 * 2
+    assert d["roofline"]["kernel"] == "k_wf_traverse" and d["roofline"]["pmc_stale"] is True  # the committed PMC pass is of the bench workload, not of this file
+
+
+@pytest.mark.gpu
 def test_cli_renders_config_json(tmp_path, small_atrium):
     import subprocess
 

@@ -145,7 +145,7 @@ def needle_measure(flat):
     return worst
 
 
-def run_case(seed, verbose=False):
+def run_case(seed, verbose=False, hook=None):
     rng = np.random.default_rng(seed)
     flat = random_scene(rng)
     W, H = int(rng.integers(8, 64)), int(rng.integers(8, 48))
@@ -311,6 +311,8 @@ def run_case(seed, verbose=False):
                 problems.append(("hybrid", float(bad), float(np.nanmax(np.abs(acc - accb))), {"gpu_vs_brute_pixels": gb, "oracle_tree_vs_brute_pixels": tb}))
             else:
                 info["oracle_tree_differs_from_brute_force"] = True
+        if hook is not None:  # tools/debug_case.py: everything a replay needs to look at single pixels / rays
+            hook(dict(flat=flat, renderer=r, oracle=orc, cam=cam, pc=pc, W=W, H=H, gbuffer=gnp, acc=acc, accr=accr, seed=seed, flags=flags, kind=kind, opts=opts))
     finally:
         r.close()
     if verbose or problems:
