@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VKRT_ABI_VERSION 2 /* 2: vkrt_scene_set_option / vkrt_reserve, vkrt_counters.traversal_faults */
+#define VKRT_ABI_VERSION 2 /* 2: vkrt_scene_set_option / vkrt_reserve, vkrt_counters.traversal_faults; options 10, 11 added in place (round 3) */
 
 enum vkrt_status {
   VKRT_OK = 0,
@@ -198,8 +198,19 @@ enum vkrt_option {
   VKRT_OPT_TRI_THRESHOLD   = 6, /* lanes with pending triangles before a wave tests them, 0 = test at once (default 1) [build]; env VKRT_TRI_THRESHOLD */
   VKRT_OPT_WF_SHARE_PERIOD = 7, /* sharing attempted on steps with (step & mask) == mask (default 0 = every step) [build]; env VKRT_WF_SHARE_PERIOD */
   VKRT_OPT_WF_SHARE_FLAGS  = 8, /* bit 0: lanes with an empty stack also donate a pending child of their current group [build]; env VKRT_WF_SHARE_FLAGS */
-  VKRT_OPT_GBUFFER_MIPS    = 9  /* NOT a scheduling knob: 1 (default) = vkrt_gbuffer_raycast samples textures like the fragment shader it replaces
+  VKRT_OPT_GBUFFER_MIPS    = 9, /* NOT a scheduling knob: 1 (default) = vkrt_gbuffer_raycast samples textures like the fragment shader it replaces
                                    (implicit LOD over the mip chain, anisotropy 4; hello_vulkan.cpp:448-454, :499), 0 = LOD 0; env VKRT_GBUFFER_MIPS */
+  VKRT_OPT_WATERTIGHT      = 10, /* NOT a scheduling knob [build]: 0 (default) = Moeller-Trumbore on pre-subtracted (v0, e1, e2) records in binary32
+                                   (what BASELINE.json's north star names); 1 = the watertight ray/triangle test of Woop, Benthin, Wald 2013 on the exact
+                                   vertices (p0, p1, p2): edge functions in ray space with a double-precision fallback on exact zeros, so a ray through a
+                                   shared edge or vertex hits one of the triangles -- what the Vulkan specification demands of traceRayEXT
+                                   (raytrace.rgen:64-75).  Hits differ from the default in the last bits of (t, u, v), and in the rare pixels where the
+                                   default leaks through an edge; the oracle implements both (orc_set_watertight).  env VKRT_WATERTIGHT */
+  VKRT_OPT_SKIP_DEAD_SHADOW_RAYS = 11, /* 0 (default) = every diffuse hit traces its shadow ray, as raytrace.rgen:79-97 does; 1 = a diffuse hit whose
+                                   contribution min(prd.hitValue * curWeight, 10) is exactly zero (light behind the surface, no emission) traces none:
+                                   raytrace.rgen:99-102 adds that zero whether or not the ray is occluded, so every pixel is bit-identical, only
+                                   vkrt_counters.rays_shadow drops.  Path-tracing mode of the wavefront pipeline only.  env VKRT_SKIP_DEAD_SHADOW_RAYS */
+  VKRT_OPT_LAST            = 11
 };
 int vkrt_scene_set_option(vkrt_scene* scene, int option, int value);
 int vkrt_scene_get_option(const vkrt_scene* scene, int option, int* value);

@@ -175,6 +175,7 @@ struct Instance
 struct Tri  // world-space triangle for traversal
 {
   V3 v0, e1, e2;
+  V3 p1, p2;  // exact world-space vertices 1 and 2 (v0 + e1 rounds away from p1): what the watertight test works on
   uint32_t gid, inst, prim;
 };
 struct TexLevel
@@ -230,6 +231,7 @@ struct orc_scene
   std::vector<Tex> tex;
   float srgb_lut[256];
   int gbufferMips = 1;  // hybrid G-buffer samples with implicit LOD (fragment shader semantics); 0 = LOD 0
+  int watertight = 0;   // ray/triangle test: 0 = Moeller-Trumbore (default), 1 = Woop-Benthin-Wald watertight (VKRT_OPT_WATERTIGHT)
   std::vector<Tri> tris;  // flattened, gid order
   // BVH
   std::vector<BvhNode> nodes;
@@ -319,6 +321,66 @@ inline bool isect_tri(V3 o, V3 d, const Tri& tr, float& t, float& u, float& v)
   return true;
 }
 
+// Watertight alternative (include/vkrt.h VKRT_OPT_WATERTIGHT): Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection", JCGT 2013,
+// on the exact vertices; what the Vulkan specification demands of traceRayEXT (raytrace.rgen:64-75).  Translate to the ray origin,
+// permute so that the dominant direction axis is z, shear, three 2D edge functions (products and differences only: a shared edge
+// gets the exact negative in the neighbouring triangle), exact zeros re-evaluated in double, no culling.  Same operation order as
+// csrc/traverse.h tri_test_wt.
+struct WtRay
+{
+  int kz;
+  float Sx, Sy, Sz;
+};
+inline WtRay wt_prepare(V3 d)
+{
+  WtRay R;
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  R.kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+  const float dz = R.kz == 0 ? d.x : (R.kz == 1 ? d.y : d.z);
+  const float dx = R.kz == 0 ? d.y : (R.kz == 1 ? d.z : d.x);
+  const float dy = R.kz == 0 ? d.z : (R.kz == 1 ? d.x : d.y);
+  R.Sx = dx / dz; R.Sy = dy / dz; R.Sz = 1.0f / dz;
+  return R;
+}
+inline V3 wt_permute(int kz, V3 v) { return kz == 0 ? v3(v.y, v.z, v.x) : (kz == 1 ? v3(v.z, v.x, v.y) : v); }
+inline bool isect_tri_wt(const WtRay& R, V3 o, const Tri& tr, float& t, float& u, float& v)
+{
+  const V3 A = wt_permute(R.kz, tr.v0 - o), B = wt_permute(R.kz, tr.p1 - o), C = wt_permute(R.kz, tr.p2 - o);
+  const float Ax = A.x - R.Sx * A.z, Ay = A.y - R.Sy * A.z;
+  const float Bx = B.x - R.Sx * B.z, By = B.y - R.Sy * B.z;
+  const float Cx = C.x - R.Sx * C.z, Cy = C.y - R.Sy * C.z;
+  float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+  if(U == 0.0f || V == 0.0f || W == 0.0f)
+  {
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+  if((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
+    return false;
+  const float det = (U + V) + W;
+  if(det == 0.0f)
+    return false;
+  const float Az = R.Sz * A.z, Bz = R.Sz * B.z, Cz = R.Sz * C.z;
+  const float T = (U * Az + V * Bz) + W * Cz;
+  const float inv = 1.0f / det;
+  t = T * inv;
+  u = V * inv;
+  v = W * inv;
+  return true;
+}
+// the scene's ray/triangle test for one ray
+struct TriTester
+{
+  bool wt;
+  WtRay R;
+  TriTester(const orc_scene& s, V3 d) : wt(s.watertight != 0), R(wt ? wt_prepare(d) : WtRay{2, 0.0f, 0.0f, 0.0f}) {}
+  bool operator()(V3 o, V3 d, const Tri& tr, float& t, float& u, float& v) const
+  {
+    return wt ? isect_tri_wt(R, o, tr, t, u, v) : isect_tri(o, d, tr, t, u, v);
+  }
+};
+
 struct RayInv
 {
   V3 o, id;  // origin, 1/direction with |d| clamped away from zero
@@ -361,11 +423,11 @@ struct Hit
 };
 
 // accept rule shared by brute force and BVH: smallest t in (tmin, tmax); ties -> smallest gid
-inline void consider(const Tri& tr, V3 o, V3 d, float tmin, Hit& best, Counters& c)
+inline void consider(const TriTester& test, const Tri& tr, V3 o, V3 d, float tmin, Hit& best, Counters& c)
 {
   float t, u, v;
   c.tris_tested++;
-  if(!isect_tri(o, d, tr, t, u, v))
+  if(!test(o, d, tr, t, u, v))
     return;
   if(!(t > tmin))
     return;
@@ -391,20 +453,22 @@ Hit closest_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counte
 {
   tapRay(o, d, tmin, tmax, false);
   Hit best{tmax, 0, 0, -1};
+  const TriTester test(s, d);
   // tmax exclusive: a hit needs t < tmax; emulate by starting best.t = tmax with tri = -1
   // (tie rule "gid < -1" never holds, so t == tmax is rejected).
   for(const Tri& tr : s.tris)
-    consider(tr, o, d, tmin, best, c);
+    consider(test, tr, o, d, tmin, best, c);
   return best;
 }
 bool any_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
 {
   tapRay(o, d, tmin, tmax, true);
+  const TriTester test(s, d);
   for(const Tri& tr : s.tris)
   {
     float t, u, v;
     c.tris_tested++;
-    if(isect_tri(o, d, tr, t, u, v) && t > tmin && t < tmax)
+    if(test(o, d, tr, t, u, v) && t > tmin && t < tmax)
       return true;
   }
   return false;
@@ -417,6 +481,7 @@ Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters
   if(s.tris.empty())
     return best;
   RayInv r{o, v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z))};
+  const TriTester test(s, d);
   int32_t stack[256];
   int sp = 0;
   int32_t cur = s.rootIsLeaf ? ~0 : 0;
@@ -426,7 +491,7 @@ Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters
     {
       const BvhLeaf& lf = s.leaves[~cur];
       for(uint32_t k = 0; k < lf.count; k++)
-        consider(s.tris[s.triOrder[lf.first + k]], o, d, tmin, best, c);
+        consider(test, s.tris[s.triOrder[lf.first + k]], o, d, tmin, best, c);
     }
     else
     {
@@ -457,6 +522,7 @@ bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c
   if(s.tris.empty())
     return false;
   RayInv r{o, v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z))};
+  const TriTester test(s, d);
   int32_t stack[256];
   int sp = 0;
   int32_t cur = s.rootIsLeaf ? ~0 : 0;
@@ -469,7 +535,7 @@ bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c
       {
         float t, u, v;
         c.tris_tested++;
-        if(isect_tri(o, d, s.tris[s.triOrder[lf.first + k]], t, u, v) && t > tmin && t < tmax)
+        if(test(o, d, s.tris[s.triOrder[lf.first + k]], t, u, v) && t > tmin && t < tmax)
           return true;
       }
     }
@@ -495,6 +561,29 @@ bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c
     cur = stack[--sp];
   }
   return false;
+}
+
+// How far outside the exact triangle the binary32 Moeller-Trumbore test above can accept a point, for ray origins within one
+// triangle length: its u, v carry an absolute error ~ eps |o - v0| / (sin(phi) cos(theta)) (phi = angle between e1 and e2) in
+// units of the edge length.  Negligible for ordinary triangles, 0.06 units for a 750-unit needle enclosing 7e-4 rad (round 3,
+// tools/fuzz_parity.py seed 1301004260: a one-triangle leaf box pruned a "hit" that the loop over all triangles finds).  The
+// closest-hit / any-hit result is DEFINED by the triangle test over all triangles, so the tree's boxes have to cover its reach:
+// the box of every triangle with sin(phi) < 1/8 is widened by 16 eps max(|e1|, |e2|) / sin(phi), capped at the triangle's length.  Same rule, same
+// operation order as the product's builders (csrc/tri_prep.h).
+inline float triSlop(V3 e1, V3 e2)
+{
+  const float l1 = (e1.x * e1.x + e1.y * e1.y) + e1.z * e1.z;
+  const float l2 = (e2.x * e2.x + e2.y * e2.y) + e2.z * e2.z;
+  const float cx = e1.y * e2.z - e1.z * e2.y, cy = e1.z * e2.x - e1.x * e2.z, cz = e1.x * e2.y - e1.y * e2.x;
+  const float a2 = (cx * cx + cy * cy) + cz * cz;
+  if(!(a2 > 0.0f))
+    return 0.0f;
+  const float len = sqrtf(l1 > l2 ? l1 : l2);
+  const float invSin = sqrtf((l1 * l2) / a2);
+  if(!(invSin > 8.0f))
+    return 0.0f;  // corners wider than ~7 degrees: inside the box tests' own margins
+  const float sl = (9.5367431640625e-07f * len) * invSin;
+  return sl < len ? sl : len;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -601,9 +690,11 @@ struct Builder
       const Tri& t = s.tris[i];
       V3 a = t.v0, b = t.v0 + t.e1, c = t.v0 + t.e2;
       Aabb bb;
-      bb.lo[0] = fminf(a.x, fminf(b.x, c.x)); bb.hi[0] = fmaxf(a.x, fmaxf(b.x, c.x));
-      bb.lo[1] = fminf(a.y, fminf(b.y, c.y)); bb.hi[1] = fmaxf(a.y, fmaxf(b.y, c.y));
-      bb.lo[2] = fminf(a.z, fminf(b.z, c.z)); bb.hi[2] = fmaxf(a.z, fmaxf(b.z, c.z));
+      bb.lo[0] = fminf(fminf(a.x, fminf(b.x, c.x)), fminf(t.p1.x, t.p2.x)); bb.hi[0] = fmaxf(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(t.p1.x, t.p2.x));
+      bb.lo[1] = fminf(fminf(a.y, fminf(b.y, c.y)), fminf(t.p1.y, t.p2.y)); bb.hi[1] = fmaxf(fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(t.p1.y, t.p2.y));
+      bb.lo[2] = fminf(fminf(a.z, fminf(b.z, c.z)), fminf(t.p1.z, t.p2.z)); bb.hi[2] = fmaxf(fmaxf(a.z, fmaxf(b.z, c.z)), fmaxf(t.p1.z, t.p2.z));
+      const float slop = triSlop(t.e1, t.e2);  // the reach of the binary32 triangle test outside the triangle (needles; see triSlop)
+      for(int k = 0; k < 3; k++) { bb.lo[k] -= slop; bb.hi[k] += slop; }
       tb[i] = bb;
       cen[i] = v3(0.5f * (bb.lo[0] + bb.hi[0]), 0.5f * (bb.lo[1] + bb.hi[1]), 0.5f * (bb.lo[2] + bb.hi[2]));
       s.triOrder[i] = i;
@@ -1623,7 +1714,7 @@ orc_scene* orc_scene_create(const vkrt_scene_desc* d)
       uint32_t i2 = s->idx[pm.firstIndex + 3 * p + 2] + pm.vertexOffset;
       V3 a = xformPoint(in, s->pos[i0]), b = xformPoint(in, s->pos[i1]), c = xformPoint(in, s->pos[i2]);
       Tri t;
-      t.v0 = a; t.e1 = b - a; t.e2 = c - a;
+      t.v0 = a; t.e1 = b - a; t.e2 = c - a; t.p1 = b; t.p2 = c;
       t.gid = gid++; t.inst = n; t.prim = p;
       s->tris.push_back(t);
     }
@@ -1921,6 +2012,10 @@ int orc_hybrid_rows_nrd(const orc_scene* s, const PushConstantRay* pc, const Glo
     }
   return 0;
 }
+
+/* Ray/triangle test of every later query on this scene: 0 = Moeller-Trumbore (default), 1 = watertight (VKRT_OPT_WATERTIGHT).  The
+ * tree need not be rebuilt (its boxes bound both vertex forms). */
+void orc_set_watertight(orc_scene* s, int on) { s->watertight = on ? 1 : 0; }
 
 /* The rays raytraceHybrid.rgen traces for ONE pixel, in order (9 floats each: o.xyz, d.xyz, tmin, tmax, any-hit flag); gpix = the
  * pixel's G-buffer texels (color4, position4, normal4, rough2).  Returns the number of floats the full log has. */

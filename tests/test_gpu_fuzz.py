@@ -25,6 +25,23 @@ def test_random_scenes_match_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("watertight", [0, 1])
+def test_needle_case_of_the_round2_campaign(watertight):
+    """Seed 1301004260 (left open in round 2 as "BVH2 layout, one hybrid pixel off by 2e-6"): a 750-unit needle whose two long
+    edges enclose 7e-4 rad.  Binary32 Moeller-Trumbore accepts a point 0.06 units beyond its tip (error of u, v ~ eps |o - v0| /
+    sin(angle)); brute force finds that hit, a one-triangle leaf box pruned it -- any tree with a tight box would, the wide layout
+    just happened not to.  Fixed in the builders: every triangle's box covers the reach of the test (csrc/tri_prep.h), so the
+    result is again a property of the triangle set; with the watertight test the point is not accepted in the first place.
+    The case is replayed with its recorded options (clustered build, BVH2 layout, megakernel mode) under both triangle tests."""
+    import fuzz_parity
+    from vkrt_amd import abi
+
+    info, problems = fuzz_parity.run_case(1301004260, force_opts={abi.VKRT_OPT_WATERTIGHT: watertight})
+    assert info["opts"].get(abi.VKRT_OPT_BVH_LAYOUT) == 0 and info["kind"] == "ploc"
+    assert not problems, problems
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("layout", [1, 0])
 def test_large_pile_of_coincident_triangles_builds_a_balanced_tree(layout):
     """Found by the campaign: ~50 k triangles of which only a handful are distinct.  Every split of the SAH top builder ties; it used

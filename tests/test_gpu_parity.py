@@ -800,3 +800,134 @@ def test_built_trees_are_structurally_sound(cornell_flat, atrium_small, kind):
                 assert c["nodes_reached"] == a["node_count"], (kind, layout, c, a["node_count"])
             if layout == 1:
                 assert c["max_depth"] == a["max_depth"] + 1 or c["max_depth"] == a["max_depth"], (c["max_depth"], a["max_depth"])
+
+
+# ---- round 3: the watertight triangle test and the dead-shadow-ray option ---------------------------------------------------------
+@pytest.mark.parametrize("kind,options", [("ploc", {}), ("sah", {}), ("lbvh", {}), ("ploc", {2: 0}), ("sah", {2: 0}), ("ploc", {1: 0}), ("ploc", {5: 0})])
+def test_watertight_option_matches_the_oracle(cornell_flat, kind, options):
+    """VKRT_OPT_WATERTIGHT on both sides (oracle set_watertight): rays bit for bit, config 1 bit-identical, the wall diagonal lit.
+    Every builder, both node layouts (option 2), the megakernel (option 1 = 0), the wavefront kernel without work sharing (5 = 0)."""
+    import oracle_py
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    orc = oracle_py.OracleScene(cornell_flat)
+    W = H = 256
+    cam = default_camera(W, H)
+    pc = make_push_constants(samples=1, depth=1, frame=0, lights_count=len(cornell_flat.lights))
+    mt, _ = orc.render(pc, cam, W, H, seed=0)
+    orc.set_watertight(True)
+    r = Renderer(cornell_flat, device=0, build=kind, options={**options, abi.VKRT_OPT_WATERTIGHT: 1})
+    assert r.get_option(abi.VKRT_OPT_WATERTIGHT) == 1
+    o, d = _ray_set(40000, 21)
+    t0, u0, v0, g0, _ = orc.trace_rays(o, d, use_bvh=False)
+    t1, u1, v1, g1 = r.trace_rays(o, d)
+    assert np.array_equal(g0, g1)
+    hit = g0 >= 0
+    for a, b in ((t0, t1), (u0, u1), (v0, v1)):
+        assert np.array_equal(a[hit].view(np.uint32), b[hit].view(np.uint32))
+    _, _, _, a0, _ = orc.trace_rays(o, d, tmin=0.001, tmax=3.0, any_hit=True, use_bvh=False)
+    _, _, _, a1 = r.trace_rays(o, d, tmin=0.001, tmax=3.0, any_hit=True)
+    assert np.array_equal(a0, a1)
+    ref, cref = orc.render(pc, cam, W, H, seed=0)
+    r.reset_counters()
+    img = r.pathtrace(pc, cam, W, H, seed=0).cpu().numpy()
+    c = r.counters()
+    assert mismatch_fraction(img, ref) == 0.0
+    assert c["rays_closest"] == cref["rays_closest"] and c["rays_shadow"] == cref["rays_shadow"] and c["traversal_faults"] == 0
+    # the known deviation of the default test (DESIGN.md section 2): camera rays through pixels (x, 255 - x) run along the back wall's
+    # diagonal; where Moeller-Trumbore lets them through to the unlit shell 0.1 behind the wall the pixel is black, the watertight
+    # test hits the wall and the pixel is lit
+    xs = np.arange(256)
+    od = np.array([np.concatenate(oracle_py.camera_ray(cam, int(x), int(255 - x), W, H)) for x in xs], np.float32)
+    t_wt, _, _, _, _ = orc.trace_rays(od[:, :3], od[:, 3:], use_bvh=False)
+    orc.set_watertight(False)
+    t_mt, _, _, _, _ = orc.trace_rays(od[:, :3], od[:, 3:], use_bvh=False)
+    orc.set_watertight(True)
+    leak = np.nonzero(t_mt - t_wt > 0.05)[0]
+    assert 1 <= len(leak) <= 16
+    # (1 spp: the hits that draw the diffuse lobe are lit, the specular ones carry no direct light at depth 1)
+    assert np.all(mt[255 - leak, leak, :3].max(-1) < 1e-6) and np.any(img[255 - leak, leak, :3].min(-1) > 0.1)
+    # deeper paths, progressive frames
+    acc_ref = acc = None
+    for f in range(2):
+        pc4 = make_push_constants(samples=2, depth=5, frame=f, lights_count=len(cornell_flat.lights))
+        acc_ref, _ = orc.render(pc4, default_camera(160, 120), 160, 120, seed=40 + f, image=acc_ref)
+        acc = r.pathtrace(pc4, default_camera(160, 120), 160, 120, seed=40 + f, image=acc)
+    assert mismatch_fraction(acc.cpu().numpy(), acc_ref) < 1e-4 and rmse(acc.cpu().numpy(), acc_ref) < RMSE_TOL
+    r.close()
+
+
+def test_watertight_option_textured_atrium_and_hybrid(atrium_small):
+    """The instanced, textured scene under the watertight test: path tracer and hybrid passes against the oracle."""
+    import oracle_py
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat, info, camkw = atrium_small
+    W, H = 256, 144
+    cam = default_camera(W, H, **camkw)
+    lights = len(flat.lights)
+    orc = oracle_py.OracleScene(flat)
+    orc.set_watertight(True)
+    r = Renderer(flat, device=0, build="ploc", options={abi.VKRT_OPT_WATERTIGHT: 1})
+    ref = img = None
+    for f in range(2):
+        pc = make_push_constants(samples=3, depth=8, frame=f, lights_count=lights)
+        ref, cref = orc.render(pc, cam, W, H, seed=50 + f, image=ref)
+        img = r.pathtrace(pc, cam, W, H, seed=50 + f, image=img)
+    got = img.cpu().numpy()
+    assert rmse(got, ref) < RMSE_TOL and mismatch_fraction(got, ref) < 1e-4
+    g = r.gbuffer_raycast(cam, W, H, lights_count=lights)
+    go = orc.gbuffer(cam, W, H, lights_count=lights)
+    for k in go:
+        assert mismatch_fraction(g[k].cpu().numpy(), go[k]) < 1e-3, k
+    pc = make_push_constants(samples=1, depth=6, frame=0, lights_count=lights)
+    pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+    acc = r.hybrid_trace(pc, cam, W, H, g, seed=9).cpu().numpy()
+    ao, _ = orc.hybrid(pc, cam, W, H, go, seed=9)
+    assert rmse(acc, ao) < RMSE_TOL and mismatch_fraction(acc, ao) < 1e-3
+    assert r.counters()["traversal_faults"] == 0
+    r.close()
+
+
+def test_watertight_needs_the_default_traversal_workgroup(cornell_flat):
+    from vkrt_amd import abi
+    from vkrt_amd.renderer import Renderer, VkrtError
+
+    with pytest.raises(VkrtError):
+        Renderer(cornell_flat, device=0, build="ploc", options={abi.VKRT_OPT_WATERTIGHT: 1, abi.VKRT_OPT_WF_TRAV_BLOCK: 256})
+
+
+@pytest.mark.parametrize("scene", ["cornell", "atrium"])
+def test_skipping_dead_shadow_rays_changes_no_pixel(cornell_flat, atrium_small, scene):
+    """VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: a diffuse hit whose contribution is exactly zero (light behind the surface, no emission)
+    emits no shadow ray.  raytrace.rgen:99-102 adds that zero either way: images bit-identical over progressive frames, the
+    closest-hit rays the same, fewer shadow rays."""
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    if scene == "cornell":
+        flat, camkw, W, H = cornell_flat, {}, 320, 200
+    else:
+        flat, camkw, W, H = atrium_small[0], atrium_small[2], 320, 180
+    cam = default_camera(W, H, **camkw)
+    out = {}
+    for skip in (0, 1):
+        r = Renderer(flat, device=0, build="ploc", options={abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: skip})
+        img = None
+        r.reset_counters()
+        for f in range(3):
+            pc = make_push_constants(samples=4, depth=8, frame=f, lights_count=len(flat.lights))
+            img = r.pathtrace(pc, cam, W, H, seed=60 + f, image=img)
+        out[skip] = (img.cpu().numpy(), r.counters())
+        r.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    c0, c1 = out[0][1], out[1][1]
+    assert c0["rays_closest"] == c1["rays_closest"] and c0["pixels"] == c1["pixels"]
+    assert c1["rays_shadow"] < c0["rays_shadow"]
+    if scene == "atrium":
+        assert c1["rays_shadow"] < 0.9 * c0["rays_shadow"]  # an interior lit by eight point lights: a good part of the picks face away

@@ -221,3 +221,88 @@ def test_fallback_light_tables_are_independent_copies_that_agree():
     for k in ("position", "color", "intensity", "type"):
         assert np.array_equal(a[k], b[k]), k
     assert gltf_flatten.reference_fallback_lights is not fallback_lights
+
+
+# ---- watertight ray/triangle test (VKRT_OPT_WATERTIGHT; what traceRayEXT is by the Vulkan specification) ------------------------
+def test_watertight_test_closes_the_cornell_wall_diagonal(cornell_flat):
+    """Config 1's camera rays through pixels (x, 255 - x) run exactly through the diagonal shared by the back wall's two triangles.
+    Binary32 Moeller-Trumbore rejects them in both (the known deviation of DESIGN.md section 2) and they reach the outer shell 0.1
+    behind the wall; the watertight test gives each of them to one of the two triangles, as the float64 restatement and a conformant
+    driver do.  Everywhere else the two tests agree on the triangle."""
+    import np_pathtrace
+
+    W = H = 256
+    cam = default_camera(W, H)
+    orc = oracle_py.OracleScene(cornell_flat)
+    yy, xx = np.mgrid[0:H, 0:W]
+    od = np.array([np.concatenate(oracle_py.camera_ray(cam, int(x), int(y), W, H)) for x, y in zip(xx.ravel(), yy.ravel())], np.float32)
+    o, d = od[:, :3], od[:, 3:]
+    t_mt, _, _, g_mt, _ = orc.trace_rays(o, d)
+    orc.set_watertight(True)
+    t_wt, u_wt, v_wt, g_wt, _ = orc.trace_rays(o, d)
+    t_wb, _, _, g_wb, _ = orc.trace_rays(o, d, use_bvh=False)
+    assert np.array_equal(g_wt, g_wb) and np.array_equal(t_wt.view(np.uint32), t_wb.view(np.uint32))  # tree walk == loop over all triangles
+    leak = np.nonzero(np.abs(t_mt - t_wt) > 1e-3)[0]
+    assert 1 <= len(leak) <= 16 and np.all(xx.ravel()[leak] + yy.ravel()[leak] == 255)
+    assert np.all(t_mt[leak] - t_wt[leak] > 0.05)  # Moeller-Trumbore: through the wall, onto the shell behind it
+    # (elsewhere a ray on a shared edge may be given to the other of the two triangles -- a different id at the same distance)
+    t64, tri64, _, _ = np_pathtrace.NpScene(cornell_flat).closest(o[leak], d[leak])
+    assert np.allclose(t64, t_wt[leak], rtol=0, atol=1e-4)  # float64: the wall
+    assert np.all((u_wt[leak] == 0.0) | (v_wt[leak] == 0.0) | (np.abs(u_wt[leak] + v_wt[leak] - 1.0) < 1e-6))  # hits ON the shared edge
+    rest = np.ones(t_mt.shape[0], bool); rest[leak] = False
+    assert np.abs(t_mt[rest] - t_wt[rest]).max() < 2e-5 and np.mean(g_mt[rest] != g_wt[rest]) < 2e-3
+
+
+def test_watertight_test_has_no_leaks_along_shared_edges_and_vertices():
+    """Rays aimed at points ON the interior edges and vertices of a randomly rotated, finely tessellated sheet (end points of the
+    edges are float32 vertices; targets are float32 combinations of them, so they sit within rounding of an edge, on either side).
+    A sheet is closed along those edges: every such ray must hit.  The watertight test never misses; Moeller-Trumbore on the same
+    rays does."""
+    from vkrt_amd.flat_scene import LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, FlatScene
+
+    rng = np.random.default_rng(11)
+    g = 24
+    xs = np.linspace(-1, 1, g + 1)
+    gx, gz = np.meshgrid(xs, xs)
+    P = np.stack([gx.ravel(), 0.05 * np.sin(3 * gx.ravel()) * np.cos(2 * gz.ravel()), gz.ravel()], -1)
+    Q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    P = (P @ Q.T * 3.7 + rng.uniform(-2, 2, 3)).astype(np.float32)
+    idx = []
+    for j in range(g):
+        for i in range(g):
+            a = j * (g + 1) + i
+            idx += [a, a + g + 1, a + 1, a + 1, a + g + 1, a + g + 2]
+    idx = np.array(idx, np.uint32)
+    V = P.shape[0]
+    pm = np.zeros(1, PRIM_DTYPE); pm[0] = (0, idx.size, 0, V, 0)
+    mats = np.zeros(1, MAT_DTYPE)
+    mats[0]["pbrBaseColorFactor"] = [0.8, 0.8, 0.8, 1.0]
+    mats[0]["pbrBaseColorTexture"] = mats[0]["metallicRoughnessTexture"] = mats[0]["normalTexture"] = mats[0]["emissiveTexture"] = -1
+    nodes = np.zeros(1, NODE_DTYPE); nodes[0]["worldMatrix"] = np.eye(4, dtype=np.float32).ravel()
+    lights = np.zeros(1, LIGHT_DTYPE); lights[0] = ((0.0, 5.0, 0.0), (1, 1, 1), 10.0, 0)
+    flat = FlatScene(P, np.tile(np.array([0, 1, 0], np.float32), (V, 1)), np.tile(np.array([1, 0, 0, 1], np.float32), (V, 1)), np.zeros((V, 2), np.float32),
+                     idx, pm, mats, lights, nodes, [])
+    orc = oracle_py.OracleScene(flat)
+    tri = idx.reshape(-1, 3)
+    # interior edges: the diagonal of every quad and the edges between quads; targets = vertices and points along those edges
+    n = 40000
+    t = tri[rng.integers(0, tri.shape[0], n)]
+    e = rng.integers(0, 3, n)
+    a, b = P[t[np.arange(n), e]], P[t[np.arange(n), (e + 1) % 3]]
+    s = rng.choice([0.0, 1.0, 0.5, 0.25, 1.0 / 3.0], n) * (rng.random(n) < 0.5) + rng.random(n) * 0.5
+    s = np.clip(s, 0, 1).astype(np.float32)[:, None]
+    target = (a * (1 - s) + b * s).astype(np.float32)
+    cen = P.mean(0)
+    keep = np.linalg.norm((target - cen) @ Q, axis=1, ord=np.inf) < 3.7 * 0.95  # stay away from the sheet's outer boundary
+    nrm = Q[:, 1]
+    o = (target + nrm * rng.uniform(2, 6, (n, 1)) + rng.normal(0, 1.0, (n, 3))).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    o, d = o[keep], d[keep]
+    _, _, _, g_mt, _ = orc.trace_rays(o, d, tmin=0.0, tmax=1e9, use_bvh=False)
+    orc.set_watertight(True)
+    _, _, _, g_wt, _ = orc.trace_rays(o, d, tmin=0.0, tmax=1e9, use_bvh=False)
+    _, _, _, g_wt_tree, _ = orc.trace_rays(o, d, tmin=0.0, tmax=1e9)
+    assert o.shape[0] > 30000
+    assert (g_wt < 0).sum() == 0, int((g_wt < 0).sum())
+    assert np.array_equal(g_wt, g_wt_tree)
+    assert (g_mt < 0).sum() > 0  # the default test does leak on these rays

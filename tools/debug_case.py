@@ -22,7 +22,10 @@ from vkrt_amd.renderer import Renderer
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("seed", type=int)
+    ap.add_argument("--watertight", action="store_true")
     a = ap.parse_args()
+    from vkrt_amd import abi as _abi
+    force = {_abi.VKRT_OPT_WATERTIGHT: 1} if a.watertight else None
 
     def hook(S):
         orc, r, pc, cam, W, H, g = S["oracle"], S["renderer"], S["pc"], S["cam"], S["W"], S["H"], S["gbuffer"]
@@ -56,7 +59,7 @@ def main():
                     print(f"    other-layout closest over the interval: {r2.trace_rays(o, d, tmin, tmax, False)}; brute: {orc.trace_rays(o, d, tmin, tmax, False, use_bvh=False)[:4]}")
         r2.close()
 
-    fuzz_parity.run_case(a.seed, verbose=True, hook=hook)
+    fuzz_parity.run_case(a.seed, verbose=True, hook=hook, force_opts=force)
 
 
 if __name__ == "__main__":

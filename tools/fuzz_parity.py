@@ -145,8 +145,10 @@ def needle_measure(flat):
     return worst
 
 
-def run_case(seed, verbose=False, hook=None):
+def run_case(seed, verbose=False, hook=None, force_opts=None):
+    """force_opts: {option: value} applied on top of the case's own draw (e.g. the watertight test for a recorded seed)."""
     rng = np.random.default_rng(seed)
+    rng3 = np.random.default_rng([seed, 3])  # round-3 options come from their own stream: the cases of earlier campaigns keep their draws
     flat = random_scene(rng)
     W, H = int(rng.integers(8, 64)), int(rng.integers(8, 48))
     if rng.random() < 0.08:  # now and then an image large enough for the sub-frame pipeline (>= 512 tiles)
@@ -171,6 +173,9 @@ def run_case(seed, verbose=False, hook=None):
     if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SHARE] = int(rng.choice([0, 4, 40]))
     if rng.random() < 0.15: opts[abi.VKRT_OPT_MODE] = 0
     if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SUBFRAMES] = int(rng.integers(1, 5))
+    if rng3.random() < 0.2: opts[abi.VKRT_OPT_WATERTIGHT] = 1               # the other triangle test, on both sides
+    if rng3.random() < 0.2: opts[abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS] = 1    # must not change a pixel
+    opts.update(force_opts or {})
     spp, depth, frames = int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(1, 3))
     L = int(rng.integers(1, len(flat.lights) + 1))
     if rng.random() < 0.05:  # long sample sequences and deep paths (pixels far out of step with each other in the paired rounds)
@@ -184,6 +189,7 @@ def run_case(seed, verbose=False, hook=None):
     flags = abi.VKRT_TRACE_SEED_INDEX_ROW_MAJOR if rng.random() < 0.5 else 0
     info = dict(seed=seed, tris=flat.instanced_triangle_count, size=(W, H), kind=kind, opts={int(k): int(v) for k, v in opts.items()}, spp=spp, depth=depth, frames=frames)
     orc = oracle_py.OracleScene(flat)
+    orc.set_watertight(opts.get(abi.VKRT_OPT_WATERTIGHT, 0) == 1)
     r = Renderer(flat, device=0, build=kind, options=opts)
     problems = []
     brute = bool(rng.random() < 0.3) and W * H * spp * frames < 6000  # the oracle's loop over all triangles as the referee
@@ -232,7 +238,7 @@ def run_case(seed, verbose=False, hook=None):
             part = part.cpu().numpy()
             if part.shape[0] != len(rows) or not np.array_equal(part.view(np.uint32), got[rows].view(np.uint32)):
                 problems.append(("shard", (count, index, strip), 0))
-        if rng.random() < 0.1 and first_frame == 0 and spp > 0 and depth > 0 and L == len(flat.lights):  # the C++ host end to end: file -> loader -> HelloVkrt -> image, against the oracle on the numpy ingest
+        if rng.random() < 0.1 and first_frame == 0 and spp > 0 and depth > 0 and L == len(flat.lights):  # the C++ host end to end (its own scene handle and oracle, default options): file -> loader -> HelloVkrt -> image, against the oracle on the numpy ingest
             import tempfile
             import gltf_export
             import gltf_flatten

@@ -6,6 +6,7 @@
 // BVH covers the whole scene.  Output is the 64-byte node / 48-byte triangle layout of
 // device_scene.h, nodes in depth-first order (a node's first child is usually the next line).
 #include "bvh_host.h"
+#include "tri_prep.h"
 
 #include <algorithm>
 #include <cmath>
@@ -237,14 +238,14 @@ void flatten_instances(const float* positions, const uint32_t* indices, const vk
       xformPoint(m, positions + 3 * (size_t)i1, b);
       xformPoint(m, positions + 3 * (size_t)i2, c);
       FlatTri ft;
-      for(int k = 0; k < 3; k++) { ft.v0[k] = a[k]; ft.e1[k] = b[k] - a[k]; ft.e2[k] = c[k] - a[k]; }
+      for(int k = 0; k < 3; k++) { ft.v0[k] = a[k]; ft.e1[k] = b[k] - a[k]; ft.e2[k] = c[k] - a[k]; ft.p1[k] = b[k]; ft.p2[k] = c[k]; }
       ft.gid = gid++; ft.inst = n; ft.prim = t;
       out.push_back(ft);
     }
   }
 }
 
-void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh& out)
+void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh& out, bool watertight)
 {
   out.nodes.clear(); out.triOrder.clear(); out.maxDepth = 0; out.sahCost = 0; out.rootRef = (int32_t)0x80000000;
   const uint32_t n = (uint32_t)tris.size();
@@ -260,15 +261,10 @@ void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh
   {
     const FlatTri& t = tris[i];
     Box b;
+    // boxes must contain what the ray/triangle test sees (both forms of the vertices) plus its reach (tri_prep.h)
+    vkrt_tri_bounds(t.v0, t.p1, t.p2, t.e1, t.e2, watertight ? 1 : 0, b.lo, b.hi);
     for(int k = 0; k < 3; k++)
-    {
-      const float p0 = t.v0[k], p1 = t.v0[k] + t.e1[k], p2 = t.v0[k] + t.e2[k];
-      // boxes must contain what the ray/triangle test sees: the test works from (v0,e1,e2), and
-      // v0+e1 may round away from the original vertex, so bound both forms.
-      b.lo[k] = std::min(p0, std::min(p1, p2));
-      b.hi[k] = std::max(p0, std::max(p1, p2));
       cx.cen[3 * (size_t)i + k] = 0.5f * (b.lo[k] + b.hi[k]);
-    }
     cx.tb[i] = b;
     cx.order[i] = i;
     all.grow(b);
@@ -294,16 +290,18 @@ void pack_tri_shade(const std::vector<FlatTri>& tris, const std::vector<uint32_t
   }
 }
 
-void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out)
+void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out, bool watertight)
 {
   out.resize(order.size() * 12);
   for(size_t s = 0; s < order.size(); s++)
   {
     const FlatTri& t = tris[order[s]];
     float* o = &out[s * 12];
-    o[0] = t.v0[0]; o[1] = t.v0[1]; o[2] = t.v0[2]; o[3] = t.e1[0];
-    o[4] = t.e1[1]; o[5] = t.e1[2]; o[6] = t.e2[0]; o[7] = t.e2[1];
-    o[8] = t.e2[2];
+    const float* r1 = watertight ? t.p1 : t.e1;
+    const float* r2 = watertight ? t.p2 : t.e2;
+    o[0] = t.v0[0]; o[1] = t.v0[1]; o[2] = t.v0[2]; o[3] = r1[0];
+    o[4] = r1[1]; o[5] = r1[2]; o[6] = r2[0]; o[7] = r2[1];
+    o[8] = r2[2];
     memcpy(&o[9], &t.gid, 4);
     memcpy(&o[10], &t.inst, 4);
     memcpy(&o[11], &t.prim, 4);
@@ -487,6 +485,11 @@ struct W8Ctx
           if(cost > bestC) { bestC = cost; bc = (int)c; bs = s; }
         }
       }
+      if(bc < 0)
+      {  // every comparison failed (NaN / inf boxes): keep the assignment total -- first free child, first free slot
+        for(size_t k = 0; k < kids.size() && bc < 0; k++) if(slotOf[k] < 0) bc = (int)k;
+        for(int s = 0; s < 8 && bs < 0; s++) if(childAt[s] < 0) bs = s;
+      }
       slotOf[bc] = bs;
       childAt[bs] = bc;
     }
@@ -581,17 +584,17 @@ struct W8Ctx
 
 }  // namespace
 
-void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out)
+void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out, bool watertight)
 {
   out = BuiltWide8{};
   if(tris.empty())
     return;
   BuiltBvh b2;
-  build_sah_host(tris, 1, b2);  // one triangle per binary leaf; the DP forms the <=3-triangle leaf children
-  collapse_wide8(b2, tris, out);
+  build_sah_host(tris, 1, b2, watertight);  // one triangle per binary leaf; the DP forms the <=3-triangle leaf children
+  collapse_wide8(b2, tris, out, watertight);
 }
 
-void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltWide8& out)
+void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltWide8& out, bool watertight)
 {
   out = BuiltWide8{};
   if(tris.empty())
@@ -604,12 +607,7 @@ void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltW
   {  // single triangle: a root with one leaf child
     W8Child c;
     const FlatTri& t = tris[b2.triOrder.empty() ? 0 : b2.triOrder[0]];
-    for(int k = 0; k < 3; k++)
-    {
-      const float p0 = t.v0[k], p1 = t.v0[k] + t.e1[k], p2 = t.v0[k] + t.e2[k];
-      c.lo[k] = std::min(p0, std::min(p1, p2));
-      c.hi[k] = std::max(p0, std::max(p1, p2));
-    }
+    vkrt_tri_bounds(t.v0, t.p1, t.p2, t.e1, t.e2, watertight ? 1 : 0, c.lo, c.hi);
     c.ref = b2.rootRef;
     kids.push_back(c);
   }

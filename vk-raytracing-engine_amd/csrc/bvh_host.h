@@ -11,6 +11,7 @@ namespace vkrt {
 struct FlatTri
 {
   float v0[3], e1[3], e2[3];
+  float p1[3], p2[3];  // the exact world-space vertices 1 and 2 (v0 + e1 rounds away from p1): what the watertight records hold
   uint32_t gid, inst, prim;
 };
 
@@ -31,14 +32,14 @@ void invert3x3_rows(const float o2w[12], float w2o[9]);
 void flatten_instances(const float* positions, const uint32_t* indices, const vkrt_prim_mesh* pm, const vkrt_node* nodes,
                        uint32_t nodeCount, std::vector<FlatTri>& out);
 
-void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh& out);
+void build_sah_host(const std::vector<FlatTri>& tris, uint32_t maxLeaf, BuiltBvh& out, bool watertight = false);
 
 // 16-byte shading records in slot order: absolute vertex indices + max(0, materialIndex) (raytrace.rchit:34-50)
 void pack_tri_shade(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, const uint32_t* indices, const vkrt_prim_mesh* pm,
                     const vkrt_node* nodes, std::vector<uint32_t>& out);
 
-// 48-byte device triangle records in slot order
-void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out);
+// 48-byte device triangle records in slot order: (v0, e1, e2, ids) for Moeller-Trumbore, (p0, p1, p2, ids) when watertight
+void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out, bool watertight = false);
 
 }  // namespace vkrt
 
@@ -63,9 +64,9 @@ struct BuiltWide8
   uint32_t nodeCount = 0;
   float sahCost = 0;
 };
-void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out);
+void build_wide8_host(const std::vector<FlatTri>& tris, BuiltWide8& out, bool watertight = false);
 // SAH-optimal collapse of an existing binary tree whose leaves hold <= 3 triangles each (ideally 1).
 // triCount0Box: bounds of the first triangle, used only when the binary root is a leaf.
-void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltWide8& out);
+void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltWide8& out, bool watertight = false);
 
 }  // namespace vkrt

@@ -93,6 +93,7 @@ struct DevScene
   uint32_t shareMinIdle;      // wide8, wavefront mode: idle lanes of a wave take over pending subtrees of busy lanes once this many are idle (0 = off)
   uint32_t gbufferMips;       // hybrid G-buffer: 1 = implicit-LOD texture() as in a fragment shader (trilinear + 4x anisotropy), 0 = LOD 0
   uint32_t shareFlags;        // bit 0: lanes whose stack is empty also donate the farthest pending child of their current group
+  uint32_t watertight;        // 1: triangle records hold (p0, p1, p2) and the kernels run the watertight test (VKRT_OPT_WATERTIGHT)
   unsigned long long* faults; // sticky tally of dropped stack pushes + step-limit exits (a walk that was cut short); must stay 0
 };
 // a traversal could not keep a pending subtree (stack full) or ran into the step bound: the result may be wrong -> make it visible
@@ -108,6 +109,10 @@ struct DevCounters
 {
   unsigned long long v[VKRT_COUNTER_SLOTS][VKRT_COUNTER_STRIDE];
 };
+
+// TraceParams.flags: the public vkrt_trace_flags (include/vkrt.h) in the low bits + internal launch-uniform switches
+#define VKRT_TRACE_PUBLIC_FLAGS 0x7u
+#define VKRT_FLAG_SKIP_DEAD_SHADOW 0x100u  // VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: a diffuse hit whose contribution is exactly zero emits no shadow ray
 
 struct TraceParams
 {

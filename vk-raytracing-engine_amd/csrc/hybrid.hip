@@ -96,7 +96,7 @@ VKRT_DEV bool pixelOf(const TraceParams& P, uint32_t& x, uint32_t& y, uint32_t& 
   return y < P.fullH;
 }
 
-template <bool WIDE>
+template <bool WIDE, bool WT>
 __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
 {
   extern __shared__ int lds_stack[];
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
     const f3 org = mk3(origin[0], origin[1], origin[2]), dir = primaryDir(P, x, y);
     RayHit hit;
     nClosest = 1;
-    traverse_any<false, WIDE>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
+    traverse_any<false, WIDE, WT>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
     if(hit.slot >= 0)
     {
       const float4 recq = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
 // One ray of every lane that has one.  SHARE: the 64 lanes of the (one-wave) workgroup walk together and lanes without a ray,
 // or done with theirs, take over pending subtrees of the others (traverse_share.h) -- the call must then be reached by all 64 lanes
 // (workgroup-uniform control flow around it).  Otherwise every lane walks alone.
-template <bool WIDE, bool SHARE>
+template <bool WIDE, bool SHARE, bool WT>
 VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int* shareLds, RayHit& hit, TravCount& tc)
 {
   if(SHARE)
@@ -265,9 +265,9 @@ VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, fl
       o = mk3(0.0f); d = mk3(1.0f, 0.0f, 0.0f); tmax = 0.0f;
     }
     if(anyHit)
-      traverse_wide8_share<false, true>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<false, true, WT>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
     else
-      traverse_wide8_share<false, false>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<false, false, WT>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
     if(!valid)
       hit.slot = -1;
   }
@@ -275,14 +275,14 @@ VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, fl
   {
     hit.slot = -1;
     if(valid)
-      traverse_any<false, WIDE>(sc, o, d, tmin, tmax, anyHit, lds, (int)threadIdx.x, (int)blockDim.x, hit, tc);
+      traverse_any<false, WIDE, WT>(sc, o, d, tmin, tmax, anyHit, lds, (int)threadIdx.x, (int)blockDim.x, hit, tc);
   }
 }
 
 // SHARE (the default with the wide layout): one wave per workgroup = one 8x8 tile, every loop and branch around a trace is
 // taken by the whole wave as long as any of its pixels needs it.  The per-pixel sequence of random numbers, rays and float
 // operations is that of rgen either way; tests/test_hybrid.py compares the two instantiations with each other and the oracle.
-template <bool WIDE, bool SHARE>
+template <bool WIDE, bool SHARE, bool WT>
 __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridParams H)
 {
   extern __shared__ int lds_stack[];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
       }
       if(anyLane(want))
       {
-        hyTrace<WIDE, SHARE>(sc, want, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, shareLds, hit, tc);
+        hyTrace<WIDE, SHARE, WT>(sc, want, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, shareLds, hit, tc);
         if(want)
         {
           nShadow++;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
         f3 rayDir = mk3(1.0f, 0.0f, 0.0f);
         if(shaded)
           rayDir = normalize3(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
-        hyTrace<WIDE, SHARE>(sc, shaded, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, shareLds, hit, tc);
+        hyTrace<WIDE, SHARE, WT>(sc, shaded, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, shareLds, hit, tc);
         if(shaded)
         {
           nShadow++;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
       while(anyLane(active))
       {
         const f3 rd = prd.rayDirection;
-        hyTrace<WIDE, SHARE>(sc, active, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, shareLds, hit, tc);
+        hyTrace<WIDE, SHARE, WT>(sc, active, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, shareLds, hit, tc);
         bool needShadow = false;
         if(active)
         {
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
         bool shadowHit = false;
         if(anyLane(needShadow))
         {
-          hyTrace<WIDE, SHARE>(sc, needShadow, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, shareLds, hit, tc);
+          hyTrace<WIDE, SHARE, WT>(sc, needShadow, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, shareLds, hit, tc);
           if(needShadow)
           {
             nShadow++;
@@ -532,10 +532,17 @@ hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], 
   H.lightsCount = lightsCount;
   const unsigned blocks = (P.tileCount * 64u + HY_BLOCK - 1) / HY_BLOCK;
   const size_t lds = (size_t)P.sc.stackCap * HY_BLOCK * sizeof(int);
+  const bool wt = P.sc.watertight != 0u;
   if(P.sc.layout == 1u)
-    hipLaunchKernelGGL(k_gbuffer<true>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  {
+    if(wt) hipLaunchKernelGGL((k_gbuffer<true, true>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+    else hipLaunchKernelGGL((k_gbuffer<true, false>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  }
   else
-    hipLaunchKernelGGL(k_gbuffer<false>, dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  {
+    if(wt) hipLaunchKernelGGL((k_gbuffer<false, true>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+    else hipLaunchKernelGGL((k_gbuffer<false, false>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+  }
   return hipGetLastError();
 }
 
@@ -557,12 +564,22 @@ hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const fl
   const unsigned block = share ? 64u : (unsigned)HY_BLOCK;
   const unsigned blocks = (P.tileCount * 64u + block - 1) / block;
   const size_t lds = (size_t)P.sc.stackCap * block * sizeof(int);
+  const bool wt = P.sc.watertight != 0u;
   if(share)
-    hipLaunchKernelGGL((k_hybrid<true, true>), dim3(blocks), dim3(block), lds, stream, H);
+  {
+    if(wt) hipLaunchKernelGGL((k_hybrid<true, true, true>), dim3(blocks), dim3(block), lds, stream, H);
+    else hipLaunchKernelGGL((k_hybrid<true, true, false>), dim3(blocks), dim3(block), lds, stream, H);
+  }
   else if(P.sc.layout == 1u)
-    hipLaunchKernelGGL((k_hybrid<true, false>), dim3(blocks), dim3(block), lds, stream, H);
+  {
+    if(wt) hipLaunchKernelGGL((k_hybrid<true, false, true>), dim3(blocks), dim3(block), lds, stream, H);
+    else hipLaunchKernelGGL((k_hybrid<true, false, false>), dim3(blocks), dim3(block), lds, stream, H);
+  }
   else
-    hipLaunchKernelGGL((k_hybrid<false, false>), dim3(blocks), dim3(block), lds, stream, H);
+  {
+    if(wt) hipLaunchKernelGGL((k_hybrid<false, false, true>), dim3(blocks), dim3(block), lds, stream, H);
+    else hipLaunchKernelGGL((k_hybrid<false, false, false>), dim3(blocks), dim3(block), lds, stream, H);
+  }
   return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@
 
 #include "device_math.h"
 #include "lbvh.h"
+#include "tri_prep.h"
 
 namespace vkrt {
 
@@ -58,7 +59,9 @@ __host__ __device__ inline float decodeOrdered(unsigned u)
   return f;
 }
 
-__global__ void k_flatten(FlatArgs A, float4* triU, float* triBox /*6 per tri*/, unsigned* sceneBounds /*lo3 hi3 ordered*/)
+// watertight != 0: the records hold the exact world-space vertices (p0, p1, p2) for the watertight test (traverse.h tri_test_wt)
+// instead of (v0, e1, e2) for Moeller-Trumbore
+__global__ void k_flatten(FlatArgs A, int watertight, float4* triU, float* triBox /*6 per tri*/, unsigned* sceneBounds /*lo3 hi3 ordered*/)
 {
   const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -86,16 +89,17 @@ __global__ void k_flatten(FlatArgs A, float4* triU, float* triBox /*6 per tri*/,
       p[k].z = ((in.o2w[8] * q.x + in.o2w[9] * q.y) + in.o2w[10] * q.z) + in.o2w[11];
     }
     const f3 v0 = p[0], e1 = p[1] - p[0], e2 = p[2] - p[0];
-    triU[3 * (size_t)gid + 0] = make_float4(v0.x, v0.y, v0.z, e1.x);
-    triU[3 * (size_t)gid + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-    triU[3 * (size_t)gid + 2] = make_float4(e2.z, __int_as_float((int)gid), __int_as_float((int)inst), __int_as_float((int)prim));
-    const float vv[3] = {v0.x, v0.y, v0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+    const f3 r1 = watertight ? p[1] : e1, r2 = watertight ? p[2] : e2;
+    triU[3 * (size_t)gid + 0] = make_float4(v0.x, v0.y, v0.z, r1.x);
+    triU[3 * (size_t)gid + 1] = make_float4(r1.y, r1.z, r2.x, r2.y);
+    triU[3 * (size_t)gid + 2] = make_float4(r2.z, __int_as_float((int)gid), __int_as_float((int)inst), __int_as_float((int)prim));
+    // the box every builder starts from (tri_prep.h): both forms of the vertices, widened by the reach of the triangle test
+    const float q0[3] = {p[0].x, p[0].y, p[0].z}, q1[3] = {p[1].x, p[1].y, p[1].z}, q2[3] = {p[2].x, p[2].y, p[2].z};
+    const float a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+    vkrt_tri_bounds(q0, q1, q2, a1, a2, watertight, lo, hi);
 #pragma unroll
     for(int k = 0; k < 3; k++)
     {
-      const float p0 = vv[k], p1 = vv[k] + a1[k], p2 = vv[k] + a2[k];
-      lo[k] = fminf(p0, fminf(p1, p2));
-      hi[k] = fmaxf(p0, fmaxf(p1, p2));
       triBox[6 * (size_t)gid + k] = lo[k];
       triBox[6 * (size_t)gid + 3 + k] = hi[k];
     }
@@ -610,7 +614,7 @@ struct Temp
   } while(0)
 
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide, bool ploc)
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide, bool ploc, bool watertight)
 {
   bool topSah = ploc;  // the FAST_TRACE device build re-builds its upper levels with SAH; the radix tree stays the pure fast build
   if(const char* e = getenv("VKRT_TOP_SAH"))  // test hook: force on / off for either builder
@@ -667,7 +671,7 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
 
   const unsigned B = 256, G = (T + B - 1) / B;
   FlatArgs A{sc.positions, sc.indices, sc.instances, dFirstGid, dFirstIndex, dVertexOffset, instCount, T};
-  hipLaunchKernelGGL(k_flatten, dim3(G), dim3(B), 0, stream, A, triU, triBox, bounds);
+  hipLaunchKernelGGL(k_flatten, dim3(G), dim3(B), 0, stream, A, watertight ? 1 : 0, triU, triBox, bounds);
   hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, T, (const float*)triBox, (const unsigned*)bounds, keysA, valsA);
   LB_TRY(hipGetLastError());
 

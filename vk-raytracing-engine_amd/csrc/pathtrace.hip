@@ -22,7 +22,7 @@
 #define VKRT_BLOCK 256
 
 
-template <bool COUNT, int MINW>
+template <bool COUNT, int MINW, bool WT>
 __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParams P)
 {
   extern __shared__ int lds_stack[];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
         nClosest++;
       }
       RayHit hit;
-      traverse<COUNT>(P.sc, o, d, tmin, tmax, shadow, stk, VKRT_BLOCK, hit, tc);
+      traverse<COUNT, WT>(P.sc, o, d, tmin, tmax, shadow, stk, VKRT_BLOCK, hit, tc);
 
       bool shadowHit = false;
       bool accumulate = true;
@@ -139,12 +139,17 @@ __global__ __launch_bounds__(VKRT_BLOCK) void k_trace_rays(DevScene sc, unsigned
     return;
   RayHit hit;
   TravCount tc;
+  const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
   if(sc.layout == 1u)
-    traverse_any<false, true>(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax, anyHit != 0,
-                              lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+  {
+    if(sc.watertight) traverse_any<false, true, true>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+    else traverse_any<false, true, false>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+  }
   else
-    traverse_any<false, false>(sc, mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]), tmin, tmax, anyHit != 0,
-                               lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+  {
+    if(sc.watertight) traverse_any<false, false, true>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+    else traverse_any<false, false, false>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+  }
   if(anyHit)
   {
     gid[i] = hit.slot >= 0 ? 0 : -1;
@@ -181,10 +186,15 @@ hipError_t vkrt_launch_pathtrace(const TraceParams& P, unsigned gridBlocks, bool
 {
   const size_t lds = (size_t)P.sc.stackCap * VKRT_BLOCK * sizeof(int);
   const dim3 g(gridBlocks), b(VKRT_BLOCK);
-  if(count)
-    hipLaunchKernelGGL((k_pathtrace<true, 1>), g, b, lds, stream, P);
+  if(P.sc.watertight != 0u)
+  {
+    if(count) hipLaunchKernelGGL((k_pathtrace<true, 1, true>), g, b, lds, stream, P);
+    else hipLaunchKernelGGL((k_pathtrace<false, 3, true>), g, b, lds, stream, P);
+  }
+  else if(count)
+    hipLaunchKernelGGL((k_pathtrace<true, 1, false>), g, b, lds, stream, P);
   else
-    hipLaunchKernelGGL((k_pathtrace<false, 3>), g, b, lds, stream, P);
+    hipLaunchKernelGGL((k_pathtrace<false, 3, false>), g, b, lds, stream, P);
   return hipGetLastError();
 }
 
@@ -192,7 +202,7 @@ int vkrt_pathtrace_block_size() { return VKRT_BLOCK; }
 
 hipError_t vkrt_pathtrace_occupancy(size_t ldsBytes, int* blocksPerCU)
 {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 3>, VKRT_BLOCK, ldsBytes);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 3, false>, VKRT_BLOCK, ldsBytes);
 }
 
 hipError_t vkrt_launch_trace_rays(const DevScene& sc, unsigned n, const float* o, const float* d, float tmin, float tmax, int anyHit,

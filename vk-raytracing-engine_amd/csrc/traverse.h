@@ -78,12 +78,88 @@ VKRT_DEV bool tri_test(f3 o, f3 d, f3 v0, f3 e1, f3 e2, float& t, float& u, floa
   return true;
 }
 
+// ---- watertight alternative (VKRT_OPT_WATERTIGHT) -----------------------------------------------------------------------------
+// The ray/triangle test of Woop, Benthin, Wald, "Watertight Ray/Triangle Intersection" (JCGT 2013), on records that hold the
+// exact vertices (p0, p1, p2): translate to the ray origin, shear so that the ray runs along +z of a permuted frame, evaluate the
+// three 2D edge functions; a shared edge gets the same two sheared end points in both triangles, so its edge function is the
+// exact negative in the neighbour (products and differences only, NO fused multiply-add here: -ffp-contract=off) and a ray
+// cannot pass between them; exact zeros are re-evaluated in double.  This is what the Vulkan specification asks of traceRayEXT
+// (raytrace.rgen:64-75).  Same operation order in oracle/oracle.cpp (isect_tri_wt).  No back-face culling (gl_RayFlagsNoneEXT).
+// Its reach outside the exact triangle is ~1e-7 of the distance for every triangle shape (vertices near the ray origin are
+// exact after the translation), where Moeller-Trumbore's grows with 1 / sin of the corner angle (tri_prep.h).
+struct WtRay
+{
+  int kz;             // dominant axis of the direction; kx = (kz + 1) % 3, ky = (kz + 2) % 3 (no swap: both windings are accepted)
+  float Sx, Sy, Sz;   // shear d[kx] / d[kz], d[ky] / d[kz] and scale 1 / d[kz]
+};
+VKRT_DEV WtRay wt_prepare(f3 d)
+{
+  WtRay R;
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  R.kz = (ax > ay) ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+  const float dz = R.kz == 0 ? d.x : (R.kz == 1 ? d.y : d.z);
+  const float dx = R.kz == 0 ? d.y : (R.kz == 1 ? d.z : d.x);
+  const float dy = R.kz == 0 ? d.z : (R.kz == 1 ? d.x : d.y);
+  R.Sx = dx / dz; R.Sy = dy / dz; R.Sz = 1.0f / dz;
+  return R;
+}
+// (x, y, z) of v in the permuted frame
+VKRT_DEV f3 wt_permute(int kz, f3 v) { return kz == 0 ? mk3(v.y, v.z, v.x) : (kz == 1 ? mk3(v.z, v.x, v.y) : v); }
+VKRT_DEV bool tri_test_wt(const WtRay& R, f3 o, f3 p0, f3 p1, f3 p2, float& t, float& u, float& v)
+{
+  const f3 A = wt_permute(R.kz, p0 - o), B = wt_permute(R.kz, p1 - o), C = wt_permute(R.kz, p2 - o);
+  const float Ax = A.x - R.Sx * A.z, Ay = A.y - R.Sy * A.z;
+  const float Bx = B.x - R.Sx * B.z, By = B.y - R.Sy * B.z;
+  const float Cx = C.x - R.Sx * C.z, Cy = C.y - R.Sy * C.z;
+  float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+  if(U == 0.0f || V == 0.0f || W == 0.0f)
+  {  // on an edge in single precision: decide it in double (products of two floats are exact there)
+    U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+    V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+    W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+  }
+  if((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
+    return false;
+  const float det = (U + V) + W;
+  if(det == 0.0f)
+    return false;
+  const float Az = R.Sz * A.z, Bz = R.Sz * B.z, Cz = R.Sz * C.z;
+  const float T = (U * Az + V * Bz) + W * Cz;
+  const float inv = 1.0f / det;
+  t = T * inv;   // barycentric weights: U -> p0, V -> p1, W -> p2; (u, v) weigh p1 and p2 like Moeller-Trumbore's
+  u = V * inv;
+  v = W * inv;
+  return true;   // (a NaN anywhere leaves t NaN: every caller's `t > tmin` rejects it)
+}
+
+// Compile-time choice of the test: per-ray constants + one entry point on a 48-byte record (a, b, c).
+template <bool WT> struct TriRay;
+template <> struct TriRay<false>
+{
+  VKRT_DEV void set(f3) {}
+  VKRT_DEV bool hit(f3 o, f3 d, float4 a, float4 b, float4 c, float& t, float& u, float& v) const
+  {
+    return tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v);
+  }
+};
+template <> struct TriRay<true>
+{
+  WtRay R;
+  VKRT_DEV void set(f3 d) { R = wt_prepare(d); }
+  VKRT_DEV bool hit(f3 o, f3, float4 a, float4 b, float4 c, float& t, float& u, float& v) const
+  {
+    return tri_test_wt(R, o, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v);
+  }
+};
+
 // stk: this lane's LDS stack column (entry k at stk[k * stride]).
-template <bool COUNT>
+template <bool COUNT, bool WT = false>
 VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* stk, int stride, RayHit& hit,
                        TravCount& tc)
 {
   const f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  TriRay<WT> tr;
+  tr.set(d);
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
   const int cap = (int)sc.stackCap;
@@ -159,7 +235,7 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
         const float4 c = tris[s * VKRT_TRI_QUADS + 2];
         if(COUNT) tc.tris++;
         float t, u, v;
-        if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
+        if(tr.hit(o, d, a, b, c, t, u, v))
         {
           if(t > tmin)
           {

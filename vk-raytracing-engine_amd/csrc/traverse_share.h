@@ -43,10 +43,12 @@ VKRT_DEV ShareRes shareRes(int* lds320)
 
 // Must be called by all 64 lanes of a one-wave workgroup (lanes without a ray pass valid = false and only help).
 // stk: this lane's stack column (stride 64 entries), res: the wave's ShareRes block.
-template <bool COUNT, bool ANYHIT>
+template <bool COUNT, bool ANYHIT, bool WT = false>
 VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, uint2* stk, ShareRes res, RayHit& hit,
                                    TravCount& tc)
 {
+  TriRay<WT> tr;
+  tr.set(d);
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
   const int stride = 64;
@@ -115,6 +117,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
         if(takes)
         {
           o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); id = mk3(ix, iy, iz); tmax = tm;
+          tr.set(d);  // (watertight: the adopted ray's shear constants, recomputed rather than shuffled)
           px = !(id.x < 0.0f); py = !(id.y < 0.0f); pz = !(id.z < 0.0f);
           octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
           G = make_uint2(ex, ey);
@@ -160,7 +163,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
             if(lane == __ffsll((long long)__ballot(1)) - 1) tc.waveTriSteps++;
           }
           float t, u, v;
-          if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v) && t > tmin)
+          if(tr.hit(o, d, a, b, c, t, u, v) && t > tmin)
           {
             if(ANYHIT)
             {

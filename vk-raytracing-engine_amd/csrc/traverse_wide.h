@@ -21,8 +21,10 @@ VKRT_DEV float ubyte_f32(unsigned w, int k) { return (float)((w >> (8 * k)) & 0x
 // Resumable per-lane traversal state: one w8_iterate() = take the nearest pending child node of the
 // current group, test its 8 children, intersect the triangles the ray's boxes touched, then pop if the
 // group is exhausted.  Used as a plain loop (traverse_wide8) and by the refilling kernel (wavefront.hip).
+template <bool WT>
 struct W8State
 {
+  TriRay<WT> tr;
   f3 o, d, id;
   float tmax, bestT, bestU, bestV;
   int bestSlot, bestGid;
@@ -32,9 +34,11 @@ struct W8State
   bool anyHit;
 };
 
-VKRT_DEV void w8_begin(const DevScene& sc, W8State& S, f3 o, f3 d, float tmax, bool anyHit)
+template <bool WT>
+VKRT_DEV void w8_begin(const DevScene& sc, W8State<WT>& S, f3 o, f3 d, float tmax, bool anyHit)
 {
   S.o = o; S.d = d;
+  S.tr.set(d);
   S.id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   S.tmax = tmax; S.bestT = tmax; S.bestU = 0.0f; S.bestV = 0.0f;
   S.bestSlot = -1; S.bestGid = -1;
@@ -118,8 +122,8 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
 }
 
 // returns true while the ray has more work
-template <bool COUNT, bool ANYHIT>
-VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk, int stride, TravCount& tc)
+template <bool COUNT, bool ANYHIT, bool WT>
+VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<WT>& S, float tmin, uint2* stk, int stride, TravCount& tc)
 {
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
@@ -174,7 +178,7 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
       if((int)lane_id() == __ffsll((long long)__ballot(1)) - 1) tc.waveTriSteps++;
     }
     float t, u, v;
-    if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v))
+    if(S.tr.hit(o, d, a, b, c, t, u, v))
     {
       if(t > tmin)
       {
@@ -217,9 +221,11 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State& S, float tmin, uint2* stk,
 // hold one, or when no lane has node work left.  A second group arriving while T is still pending is parked on the
 // top end of the lane's stack column (at most VKRT_W8_MAX_POSTPONED per lane, else tested at once).
 // The result does not depend on the order (closest = smallest t, ties -> smallest triangle id; any = exists).
-template <bool COUNT, bool ANYHIT>
+template <bool COUNT, bool ANYHIT, bool WT>
 VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, uint2* stk, int stride, RayHit& hit, TravCount& tc)
 {
+  TriRay<WT> tr;
+  tr.set(d);
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
   const int cap = (int)(sc.stackCap >> 1);
@@ -249,7 +255,7 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
       if((int)lane_id() == __ffsll((long long)__ballot(1)) - 1) tc.waveTriSteps++;
     }
     float t, u, v;
-    if(tri_test(o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v) && t > tmin)
+    if(tr.hit(o, d, a, b, c, t, u, v) && t > tmin)
     {
       if(ANYHIT)
       {
@@ -346,28 +352,28 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
   hit.t = bestT; hit.u = bestU; hit.v = bestV; hit.slot = bestSlot;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool WT = false>
 VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, uint2* stk, int stride, RayHit& hit,
                              TravCount& tc)
 {
   if(sc.triThreshold != 0u)  // launch-uniform
   {
     if(anyHit)
-      traverse_wide8_postpone<COUNT, true>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
+      traverse_wide8_postpone<COUNT, true, WT>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
     else
-      traverse_wide8_postpone<COUNT, false>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
+      traverse_wide8_postpone<COUNT, false, WT>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
     return;
   }
-  W8State S;
+  W8State<WT> S;
   w8_begin(sc, S, o, d, tmax, anyHit);
   if(S.G.y != 0u)
   {
     if(anyHit)  // workgroup-uniform in the wavefront kernels: two specialised loops, no per-triangle branch
-      while(w8_iterate<COUNT, true>(sc, S, tmin, stk, stride, tc))
+      while(w8_iterate<COUNT, true, WT>(sc, S, tmin, stk, stride, tc))
       {
       }
     else
-      while(w8_iterate<COUNT, false>(sc, S, tmin, stk, stride, tc))
+      while(w8_iterate<COUNT, false, WT>(sc, S, tmin, stk, stride, tc))
       {
       }
   }
@@ -375,12 +381,12 @@ VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float t
 }
 
 // layout dispatch used by the kernels: stkWords = this lane's LDS stack column (4-byte words, stride in words)
-template <bool COUNT, bool WIDE>
+template <bool COUNT, bool WIDE, bool WT = false>
 VKRT_DEV void traverse_any(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int tid, int block, RayHit& hit,
                            TravCount& tc)
 {
   if(WIDE)
-    traverse_wide8<COUNT>(sc, o, d, tmin, tmax, anyHit, ((uint2*)lds) + tid, block, hit, tc);
+    traverse_wide8<COUNT, WT>(sc, o, d, tmin, tmax, anyHit, ((uint2*)lds) + tid, block, hit, tc);
   else
-    traverse<COUNT>(sc, o, d, tmin, tmax, anyHit, lds + tid, block, hit, tc);
+    traverse<COUNT, WT>(sc, o, d, tmin, tmax, anyHit, lds + tid, block, hit, tc);
 }

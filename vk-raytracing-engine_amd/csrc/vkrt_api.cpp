@@ -81,7 +81,7 @@ struct vkrt_scene
   WfTiming wfTiming{};
   bool wfTimed = false;
   // execution options (include/vkrt.h vkrt_option); index = option id
-  int opt[10] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1};
+  int opt[VKRT_OPT_LAST + 1] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1, 0, 0};
   bool wavefront = true;  // execution mode the acceleration structure was built for (opt[VKRT_OPT_MODE] at vkrt_accel_build)
 };
 
@@ -131,8 +131,18 @@ int validate(const vkrt_scene_desc* d)
                     p.vertexCount);
   }
   for(uint32_t i = 0; i < d->node_count; i++)
+  {
     if(d->nodes[i].primMesh < 0 || (uint32_t)d->nodes[i].primMesh >= d->prim_mesh_count)
       return fail(VKRT_ERR_INVALID_ARGUMENT, "node %u: primMesh %d out of range", i, d->nodes[i].primMesh);
+    for(int k = 0; k < 16; k++)
+      if(!std::isfinite(d->nodes[i].worldMatrix[k]))
+        return fail(VKRT_ERR_INVALID_ARGUMENT, "node %u: worldMatrix[%d] is not finite", i, k);
+  }
+  // the builders compare and quantise boxes: NaN / inf coordinates have no place in an acceleration structure (a Vulkan driver is
+  // free to drop such triangles; here they are refused up front)
+  for(size_t i = 0; i < (size_t)d->vertex_count * 3; i++)
+    if(!std::isfinite(d->positions[i]))
+      return fail(VKRT_ERR_INVALID_ARGUMENT, "positions[%zu] (vertex %zu) is not finite", i, i / 3);
   for(uint32_t i = 0; i < d->material_count; i++)
   {
     const GltfPBRMaterial& m = d->materials[i];
@@ -191,7 +201,7 @@ int clampOption(int option, int v)
     case VKRT_OPT_TRI_THRESHOLD: return std::max(0, std::min(65, v));
     case VKRT_OPT_WF_SHARE_PERIOD: return std::max(0, std::min(255, v));
     case VKRT_OPT_WF_SHARE_FLAGS: return v & 1;
-    case VKRT_OPT_GBUFFER_MIPS: return v ? 1 : 0;
+    case VKRT_OPT_GBUFFER_MIPS: case VKRT_OPT_WATERTIGHT: case VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: return v ? 1 : 0;
   }
   return v;
 }
@@ -205,7 +215,8 @@ void optionsFromEnvironment(vkrt_scene* s)
   const struct { const char* name; int option; } ints[] = {{"VKRT_WF_SUBFRAMES", VKRT_OPT_WF_SUBFRAMES}, {"VKRT_WF_TRAV_BLOCK", VKRT_OPT_WF_TRAV_BLOCK},
                                                           {"VKRT_WF_SHARE", VKRT_OPT_WF_SHARE}, {"VKRT_TRI_THRESHOLD", VKRT_OPT_TRI_THRESHOLD},
                                                           {"VKRT_WF_SHARE_PERIOD", VKRT_OPT_WF_SHARE_PERIOD}, {"VKRT_WF_SHARE_FLAGS", VKRT_OPT_WF_SHARE_FLAGS},
-                                                          {"VKRT_GBUFFER_MIPS", VKRT_OPT_GBUFFER_MIPS}};
+                                                          {"VKRT_GBUFFER_MIPS", VKRT_OPT_GBUFFER_MIPS}, {"VKRT_WATERTIGHT", VKRT_OPT_WATERTIGHT},
+                                                          {"VKRT_SKIP_DEAD_SHADOW_RAYS", VKRT_OPT_SKIP_DEAD_SHADOW_RAYS}};
   for(const auto& k : ints)
     if((e = getenv(k.name)))
       s->opt[k.option] = clampOption(k.option, atoi(e));
@@ -449,7 +460,7 @@ int vkrt_scene_set_option(vkrt_scene* s, int option, int value)
 {
   if(!s)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "scene is NULL");
-  if(option < VKRT_OPT_MODE || option > VKRT_OPT_GBUFFER_MIPS)
+  if(option < VKRT_OPT_MODE || option > VKRT_OPT_LAST)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
   if(clampOption(option, value) != value)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "option %d: value %d out of range", option, value);
@@ -461,7 +472,7 @@ int vkrt_scene_get_option(const vkrt_scene* s, int option, int* value)
 {
   if(!s || !value)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
-  if(option < VKRT_OPT_MODE || option > VKRT_OPT_GBUFFER_MIPS)
+  if(option < VKRT_OPT_MODE || option > VKRT_OPT_LAST)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
   *value = s->opt[option];
   return VKRT_OK;
@@ -481,7 +492,10 @@ int vkrt_reserve(vkrt_scene* s, const vkrt_shard* shard, void* hip_stream)
   const uint64_t tiles = (uint64_t)((shard->full_width + 7) / 8) * ((vkrt_shard_rows(shard) + 7) / 8);
   if(tiles * 64 >= 0xFFFFFFFFull)
     return fail(VKRT_ERR_UNSUPPORTED, "launch too large");
-  if(tiles == 0 || s->opt[VKRT_OPT_MODE] != 1)
+  // the mode that counts is the one the acceleration structure was built for (vkrt_pathtrace and vkrt_hybrid_trace look at
+  // s->wavefront, not at an option that may have changed since); before a build, the option is the best guess there is
+  const bool wavefront = s->built ? s->wavefront : useWavefront(s);
+  if(tiles == 0 || !wavefront)
     return VKRT_OK;  // the megakernel keeps its state in registers / LDS
   return ensureWorkingSet(s, (uint32_t)tiles * 64u, (hipStream_t)hip_stream);
 }
@@ -506,6 +520,11 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   s->info = vkrt_accel_info{};
   s->info.build_flags = wantPloc ? VKRT_BUILD_PLOC_GPU : wantLbvh ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
   s->wavefront = useWavefront(s);
+  const bool watertight = s->opt[VKRT_OPT_WATERTIGHT] != 0;
+  if(watertight && useWavefront(s) && s->opt[VKRT_OPT_WF_TRAV_BLOCK] != 64)
+    return fail(VKRT_ERR_UNSUPPORTED, "VKRT_OPT_WATERTIGHT is built for the default 64-thread traversal workgroups (VKRT_OPT_WF_TRAV_BLOCK = %d)",
+                s->opt[VKRT_OPT_WF_TRAV_BLOCK]);
+  s->dev.watertight = watertight ? 1u : 0u;
 
   if(wantSah)
   {
@@ -521,15 +540,15 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     vkrt::BuiltWide8 w8;
     if(wide)
     {
-      vkrt::build_wide8_host(tris, w8);
-      vkrt::pack_triangles(tris, w8.triOrder, packed);
+      vkrt::build_wide8_host(tris, w8, watertight);
+      vkrt::pack_triangles(tris, w8.triOrder, packed, watertight);
       nodeData = w8.nodes.data();
       nodeBytesUsed = w8.nodes.size() * sizeof(uint32_t);
     }
     else
     {
-      vkrt::build_sah_host(tris, 4, bvh);
-      vkrt::pack_triangles(tris, bvh.triOrder, packed);
+      vkrt::build_sah_host(tris, 4, bvh, watertight);
+      vkrt::pack_triangles(tris, bvh.triOrder, packed, watertight);
       nodeData = bvh.nodes.data();
       nodeBytesUsed = bvh.nodes.size() * sizeof(float);
     }
@@ -581,7 +600,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     // binary tree keeps one triangle per leaf and is collapsed into wide8 nodes by the same SAH-optimal DP as the SAH
     // path -- on the device too (wide_collapse.hip); nothing but four statistics words comes back to the host.
     // VKRT_BUILD_PLOC_GPU: same pipeline with the radix tree replaced by locally-ordered clustering (ploc.hip)
-    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide, wantPloc);
+    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide, wantPloc, watertight);
     if(rc != VKRT_OK)
       return fail(rc, "%s build failed: %s", wantPloc ? "PLOC" : "LBVH", r.error.c_str());
     s->info.triangle_count = r.triCount;
@@ -626,15 +645,23 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
         b2.triOrder[k] = k;
         const float* t = &trisHost[(size_t)k * 12];
         vkrt::FlatTri& ft = tris[k];
-        ft.v0[0] = t[0]; ft.v0[1] = t[1]; ft.v0[2] = t[2]; ft.e1[0] = t[3]; ft.e1[1] = t[4]; ft.e1[2] = t[5];
-        ft.e2[0] = t[6]; ft.e2[1] = t[7]; ft.e2[2] = t[8];
+        for(int c = 0; c < 3; c++)
+        {
+          ft.v0[c] = t[c];
+          // records hold (v0, e1, e2) or, watertight, (p0, p1, p2): the other form is re-derived (p1 = v0 + e1 is not the exact vertex,
+          // but the boxes below only grow by it)
+          ft.e1[c] = watertight ? t[3 + c] - t[c] : t[3 + c];
+          ft.e2[c] = watertight ? t[6 + c] - t[c] : t[6 + c];
+          ft.p1[c] = watertight ? t[3 + c] : t[c] + t[3 + c];
+          ft.p2[c] = watertight ? t[6 + c] : t[c] + t[6 + c];
+        }
         memcpy(&ft.gid, &t[9], 4); memcpy(&ft.inst, &t[10], 4); memcpy(&ft.prim, &t[11], 4);
       }
       vkrt::BuiltWide8 w8;
-      vkrt::collapse_wide8(b2, tris, w8);
+      vkrt::collapse_wide8(b2, tris, w8, watertight);
       std::vector<float> packed;
       std::vector<uint32_t> shadeRec;
-      vkrt::pack_triangles(tris, w8.triOrder, packed);
+      vkrt::pack_triangles(tris, w8.triOrder, packed, watertight);
       vkrt::pack_tri_shade(tris, w8.triOrder, s->indices.data(), s->primMeshes.data(), s->nodes.data(), shadeRec);
       HIP_TRY(hipMalloc(&s->accelNodes, std::max<size_t>(w8.nodes.size() * 4, 80)));
       HIP_TRY(hipMalloc(&s->accelTris, std::max<size_t>(packed.size() * 4, 48)));
@@ -752,7 +779,9 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   memcpy(P.viewInverse, cam->viewInverse.m, sizeof P.viewInverse);
   memcpy(P.projInverse, cam->projInverse.m, sizeof P.projInverse);
   P.seed = opts ? opts->seed : 0u;
-  P.flags = opts ? opts->flags : 0u;
+  P.flags = (opts ? opts->flags : 0u) & VKRT_TRACE_PUBLIC_FLAGS;
+  if(s->opt[VKRT_OPT_SKIP_DEAD_SHADOW_RAYS])
+    P.flags |= VKRT_FLAG_SKIP_DEAD_SHADOW;  // internal bit (device_scene.h)
   P.fullW = shard->full_width;
   P.fullH = shard->full_height;
   const bool sharded = shard->shard_count > 1;
@@ -797,7 +826,7 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
     HIP_TRY(hipEventRecord(s->evStart, stream));
     WfOptions wo;
     wo.subframes = s->opt[VKRT_OPT_WF_SUBFRAMES];
-    wo.travBlock = s->opt[VKRT_OPT_WF_TRAV_BLOCK];
+    wo.travBlock = s->dev.watertight ? 64 : s->opt[VKRT_OPT_WF_TRAV_BLOCK];  // (watertight kernels exist for the default workgroup only)
     HIP_TRY(vkrt_launch_wavefront(P, s->wf, wo, count, stream, timing, &s->wfAsync));
     HIP_TRY(hipEventRecord(s->evStop, stream));
     s->timed = true;
@@ -837,7 +866,7 @@ int fillParams(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* c
   memcpy(P.viewInverse, cam->viewInverse.m, sizeof P.viewInverse);
   memcpy(P.projInverse, cam->projInverse.m, sizeof P.projInverse);
   P.seed = opts ? opts->seed : 0u;
-  P.flags = opts ? opts->flags : 0u;
+  P.flags = (opts ? opts->flags : 0u) & VKRT_TRACE_PUBLIC_FLAGS;  // (the hybrid passes never skip shadow rays: hitDists needs their result)
   P.fullW = shard->full_width;
   P.fullH = shard->full_height;
   const bool sharded = shard->shard_count > 1;
@@ -963,7 +992,7 @@ int hybridImpl(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* c
     HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, vkrt_wf_hybrid_tmp(s->wf), stream));
     HybridGi G{(const float4*)g->color, (const float4*)g->position, (const float4*)g->normal, (const float2*)g->roughMetal, (float4*)accum,
                nrd ? (float4*)nrd->diffRadianceHitDist : nullptr, nrd ? nrd->viewZ : nullptr};
-    HIP_TRY(vkrt_launch_hybrid_gi(P, s->wf, G, (unsigned)s->opt[VKRT_OPT_WF_TRAV_BLOCK], stream));
+    HIP_TRY(vkrt_launch_hybrid_gi(P, s->wf, G, s->dev.watertight ? 64u : (unsigned)s->opt[VKRT_OPT_WF_TRAV_BLOCK], stream));
   }
   else
     HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, nullptr, stream));
@@ -1118,7 +1147,7 @@ int vkrt_debug_check_accel(vkrt_scene* s, vkrt_accel_check* out)
     {
       float p[3];
       for(int k = 0; k < 3; k++)
-        p[k] = v == 0 ? t[k] : (v == 1 ? t[k] + t[3 + k] : t[k] + t[6 + k]);
+        p[k] = v == 0 ? t[k] : (s->dev.watertight ? t[3 * v + k] : (v == 1 ? t[k] + t[3 + k] : t[k] + t[6 + k]));
       for(const Bound& b : chain)
         for(int k = 0; k < 3; k++)
           if(!(p[k] >= b.lo[k] && p[k] <= b.hi[k])) { out->box_violations++; break; }

@@ -230,8 +230,8 @@ VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int ki
 }
 
 // ---- traversal: one thread per queued ray, workgroups homogeneous in ray kind -----------------------------------
-template <bool COUNT, bool WIDE, int TB>
-__global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
+template <bool COUNT, bool WIDE, int TB, bool WT = false>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WT && WIDE && TB == 64 ? 5 : 1))) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
 {
   extern __shared__ int lds_stack[];
   const int par = round & 1;
@@ -275,15 +275,15 @@ __global__ __launch_bounds__(TB) void k_wf_traverse(const TraceParams P, const W
     // the whole wave walks together: lanes past the end of the stream have no ray of their own but help
     uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
     if(anyHit)
-      traverse_wide8_share<COUNT, true>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<COUNT, true, WT>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
     else
-      traverse_wide8_share<COUNT, false>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<COUNT, false, WT>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
     if(valid)
       storeHit(P, B, par, kind, qi, hit);
   }
   else if(valid)
   {
-    traverse_any<COUNT, WIDE>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc);
+    traverse_any<COUNT, WIDE, WT>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc);
     storeHit(P, B, par, kind, qi, hit);
   }
   if(COUNT)
@@ -400,7 +400,11 @@ VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const Hybr
     else
       missShader(P.pc, L.prd);
     segmentTerms(L, contrib, nextWeight);
-    if(!L.prd.isSpecular && L.prd.depth != 100u)  // rgen:79: a shadow ray decides whether this segment contributes
+    // VKRT_OPT_SKIP_DEAD_SHADOW_RAYS (launch-uniform, path-tracing mode only): rgen:99-102 adds `contrib` when the shadow ray is
+    // not occluded; a contribution of exactly (+-0, +-0, +-0) -- light behind the surface and no emission, or a zero weight --
+    // leaves hitValue bit for bit as it is either way (x + 0 = x; the sum is never -0), so the ray need not be traced
+    const bool dead = !HYBRID && (P.flags & VKRT_FLAG_SKIP_DEAD_SHADOW) != 0u && contrib.x == 0.0f && contrib.y == 0.0f && contrib.z == 0.0f;
+    if(!L.prd.isSpecular && L.prd.depth != 100u && !dead)  // rgen:79: a shadow ray decides whether this segment contributes
       to = (L.prd.depth + 1u < (uint32_t)P.pc.depth) ? WF_P : WF_S;  // not the last segment: the next closest-hit ray rides along
     else if(HYBRID)
       to = advanceSegmentHybrid(P, G, L, false, contrib, nextWeight, 0.0f) ? WF_C : -1;
@@ -559,6 +563,36 @@ void vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B)
   B->capacity = pathCapacity;
 }
 
+// One traversal launch: the instantiation for (instrumented?, node layout, workgroup size, triangle test).  The watertight test is
+// built for the default 64-thread workgroups only (vkrt_accel_build refuses the other sizes with VKRT_OPT_WATERTIGHT).
+static void launchTraverse(const TraceParams& P, const WfBuffers& B, int r, unsigned travBlock, bool count, dim3 tg, size_t tlds, hipStream_t stream)
+{
+  const bool wide = P.sc.layout == 1u, wt = P.sc.watertight != 0u;
+  const dim3 tb(travBlock);
+#define VKRT_TRAV_LAUNCH(C, W, TB, WT) hipLaunchKernelGGL((k_wf_traverse<C, W, TB, WT>), tg, tb, tlds, stream, P, B, r)
+  if(travBlock == 64 && wt)
+  {
+    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 64, true); else VKRT_TRAV_LAUNCH(false, true, 64, true); }
+    else { if(count) VKRT_TRAV_LAUNCH(true, false, 64, true); else VKRT_TRAV_LAUNCH(false, false, 64, true); }
+  }
+  else if(travBlock == 64)
+  {
+    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 64, false); else VKRT_TRAV_LAUNCH(false, true, 64, false); }
+    else { if(count) VKRT_TRAV_LAUNCH(true, false, 64, false); else VKRT_TRAV_LAUNCH(false, false, 64, false); }
+  }
+  else if(travBlock == 128)
+  {
+    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 128, false); else VKRT_TRAV_LAUNCH(false, true, 128, false); }
+    else { if(count) VKRT_TRAV_LAUNCH(true, false, 128, false); else VKRT_TRAV_LAUNCH(false, false, 128, false); }
+  }
+  else
+  {
+    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 256, false); else VKRT_TRAV_LAUNCH(false, true, 256, false); }
+    else { if(count) VKRT_TRAV_LAUNCH(true, false, 256, false); else VKRT_TRAV_LAUNCH(false, false, 256, false); }
+  }
+#undef VKRT_TRAV_LAUNCH
+}
+
 static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsigned travBlock, bool count, hipStream_t stream, WfTiming* timing);
 
 hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, bool count, hipStream_t stream, WfTiming* timing,
@@ -607,7 +641,6 @@ static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsig
   if(P.pc.samples <= 0 || P.pc.depth <= 0)
     return hipGetLastError();
   const dim3 bb(WF_BLOCK);
-  const bool wide = P.sc.layout == 1u;
   // a sample takes at most depth + 1 rounds: its first closest-hit ray, then one round per further segment (the shadow ray of
   // segment k travels with the closest-hit ray of segment k + 1), then the shadow ray of its last segment
   const int rounds = P.pc.samples * (P.pc.depth + 1);
@@ -615,30 +648,14 @@ static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsig
     timing->used = 0;
   // every path holds one record and a record at most two rays; +4 blocks for the partial tails of the four ray kinds.
   // One wavefront per workgroup by default: a finished wave frees its slot and LDS without waiting for three others.
-  const dim3 tg(2 * ((work + travBlock - 1) / travBlock) + 4), tb(travBlock);
+  const dim3 tg(2 * ((work + travBlock - 1) / travBlock) + 4);
   const size_t tlds = (size_t)P.sc.stackCap * travBlock * sizeof(int);
   for(int r = 0; r < rounds; r++)
   {
     const bool timed = timing && timing->events && 2 * (timing->used + 1) <= timing->capacity;
     if(timed)
       (void)hipEventRecord(timing->events[2 * timing->used], stream);
-#define VKRT_TRAV_LAUNCH(C, W, TB) hipLaunchKernelGGL((k_wf_traverse<C, W, TB>), tg, tb, tlds, stream, P, B, r)
-    if(travBlock == 64)
-    {
-      if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 64); else VKRT_TRAV_LAUNCH(false, true, 64); }
-      else { if(count) VKRT_TRAV_LAUNCH(true, false, 64); else VKRT_TRAV_LAUNCH(false, false, 64); }
-    }
-    else if(travBlock == 128)
-    {
-      if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 128); else VKRT_TRAV_LAUNCH(false, true, 128); }
-      else { if(count) VKRT_TRAV_LAUNCH(true, false, 128); else VKRT_TRAV_LAUNCH(false, false, 128); }
-    }
-    else
-    {
-      if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 256); else VKRT_TRAV_LAUNCH(false, true, 256); }
-      else { if(count) VKRT_TRAV_LAUNCH(true, false, 256); else VKRT_TRAV_LAUNCH(false, false, 256); }
-    }
-#undef VKRT_TRAV_LAUNCH
+    launchTraverse(P, B, r, travBlock, count, tg, tlds, stream);
     if(timed)
     {
       (void)hipEventRecord(timing->events[2 * timing->used + 1], stream);
@@ -666,27 +683,12 @@ hipError_t vkrt_launch_hybrid_gi(const TraceParams& P, const WfBuffers& B, const
   hipLaunchKernelGGL(k_hy_gi_init, dim3(blocks), dim3(WF_BLOCK), 0, stream, P, B, G, (const uint2*)vkrt_wf_hybrid_tmp(B));
   // the GI path is one sample that starts at depth 1: at most pc.depth - 1 segments, i.e. pc.depth rounds of the paired pipeline
   const int rounds = P.pc.depth;
-  const bool wide = P.sc.layout == 1u;
   const unsigned tbs = (travBlock == 256u || travBlock == 128u) ? travBlock : 64u;
-  const dim3 tg(2 * ((work + tbs - 1) / tbs) + 4), tb(tbs);
+  const dim3 tg(2 * ((work + tbs - 1) / tbs) + 4);
   const size_t tlds = (size_t)P.sc.stackCap * tbs * sizeof(int);
   for(int r = 0; r < rounds; r++)
   {
-    if(tbs == 64u)
-    {
-      if(wide) hipLaunchKernelGGL((k_wf_traverse<false, true, 64>), tg, tb, tlds, stream, P, B, r);
-      else hipLaunchKernelGGL((k_wf_traverse<false, false, 64>), tg, tb, tlds, stream, P, B, r);
-    }
-    else if(tbs == 128u)
-    {
-      if(wide) hipLaunchKernelGGL((k_wf_traverse<false, true, 128>), tg, tb, tlds, stream, P, B, r);
-      else hipLaunchKernelGGL((k_wf_traverse<false, false, 128>), tg, tb, tlds, stream, P, B, r);
-    }
-    else
-    {
-      if(wide) hipLaunchKernelGGL((k_wf_traverse<false, true, 256>), tg, tb, tlds, stream, P, B, r);
-      else hipLaunchKernelGGL((k_wf_traverse<false, false, 256>), tg, tb, tlds, stream, P, B, r);
-    }
+    launchTraverse(P, B, r, tbs, false, tg, tlds, stream);
     hipLaunchKernelGGL(k_wf_shade_hybrid, dim3(blocks + 3), dim3(WF_BLOCK), 0, stream, P, B, G, r);
   }
   return hipGetLastError();

@@ -336,6 +336,11 @@ __global__ void k_w8_write(Emit E, uint32_t lvl)
         if(cost > bestC) { bestC = cost; bc = c; bs = s; }
       }
     }
+    if(bc < 0)
+    {  // every comparison failed (NaN / inf boxes from non-finite geometry): keep the assignment total -- first free child, first free slot
+      for(int c = 0; c < n && bc < 0; c++) if(slotOf[c] < 0) bc = c;
+      for(int s = 0; s < 8 && bs < 0; s++) if(childAt[s] < 0) bs = s;
+    }
     slotOf[bc] = bs;
     childAt[bs] = bc;
   }
