@@ -210,7 +210,17 @@ enum vkrt_option {
                                    contribution min(prd.hitValue * curWeight, 10) is exactly zero (light behind the surface, no emission) traces none:
                                    raytrace.rgen:99-102 adds that zero whether or not the ray is occluded, so every pixel is bit-identical, only
                                    vkrt_counters.rays_shadow drops.  Path-tracing mode of the wavefront pipeline only.  env VKRT_SKIP_DEAD_SHADOW_RAYS */
-  VKRT_OPT_LAST            = 11
+  VKRT_OPT_ANYHIT_DISSOLVE = 12, /* [build] the any-hit alpha / dissolve stage of raytrace_rahit_todo.glsl:23-37 (hello_vulkan.cpp:1185-1191 keeps its
+                                   registration commented out; every ray of the reference is gl_RayFlagsOpaqueEXT): 0 (default) = all geometry opaque,
+                                   as the reference runs; 1 = a candidate hit on a triangle whose material has dissolve < 1 is ignored when dissolve == 0
+                                   and otherwise with probability 1 - dissolve, for closest-hit and shadow rays of both modes (not for the ray-cast
+                                   G-buffer: a raster pass has no any-hit stage).  The shader is written against the dead OBJ pipeline's WaveFrontMaterial;
+                                   on the glTF material the live pipeline has, dissolve = pbrBaseColorFactor.a and "illum == 4" = dissolve < 1.  The GLSL
+                                   draws rnd(prd.seed) per invocation, but Vulkan defines neither the order nor the number of any-hit invocations, so the
+                                   decision here is a pure function of the ray and the triangle: rnd(tea(triangle id, prd.seed when the ray is traced)) >
+                                   dissolve; prd.seed itself is not advanced.  The result stays a property of the triangle set (any tree, any schedule);
+                                   the oracle implements the same rule (orc_set_dissolve).  env VKRT_ANYHIT_DISSOLVE */
+  VKRT_OPT_LAST            = 12
 };
 int vkrt_scene_set_option(vkrt_scene* scene, int option, int value);
 int vkrt_scene_get_option(const vkrt_scene* scene, int option, int* value);

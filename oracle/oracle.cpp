@@ -232,6 +232,7 @@ struct orc_scene
   float srgb_lut[256];
   int gbufferMips = 1;  // hybrid G-buffer samples with implicit LOD (fragment shader semantics); 0 = LOD 0
   int watertight = 0;   // ray/triangle test: 0 = Moeller-Trumbore (default), 1 = Woop-Benthin-Wald watertight (VKRT_OPT_WATERTIGHT)
+  int dissolve = 0;     // any-hit alpha / dissolve (raytrace_rahit_todo.glsl): 0 = every geometry opaque (what the reference runs), 1 = on
   std::vector<Tri> tris;  // flattened, gid order
   // BVH
   std::vector<BvhNode> nodes;
@@ -369,15 +370,43 @@ inline bool isect_tri_wt(const WtRay& R, V3 o, const Tri& tr, float& t, float& u
   v = W * inv;
   return true;
 }
-// the scene's ray/triangle test for one ray
+// Any-hit stage (include/vkrt.h VKRT_OPT_ANYHIT_DISSOLVE; reference raytrace_rahit_todo.glsl:23-37, never compiled there and written
+// against the dead OBJ pipeline's WaveFrontMaterial): a candidate hit on a non-opaque material is ignored when the material's
+// dissolve is 0, and otherwise with probability 1 - dissolve.  Mapped onto the glTF material the live pipeline has:
+// dissolve = pbrBaseColorFactor.a, "illum == 4" = dissolve < 1.  The GLSL draws rnd(prd.seed) per invocation; Vulkan leaves both
+// the order and the number of any-hit invocations to the implementation, so no sequence of draws can be THE reference's.  The
+// decision is therefore a pure function of the ray and the triangle -- rnd(tea(gid, seed of the payload when the ray is traced))
+// -- which makes the result a property of the triangle set like everything else here, and prd.seed is left as it is.
+inline bool dissolveIgnores(float alpha, uint32_t gid, uint32_t raySeed)
+{
+  if(alpha == 0.0f)
+    return true;
+  uint32_t st = tea(gid, raySeed);
+  return rnd(st) > alpha;
+}
+// the scene's ray/triangle test (+ any-hit stage) for one ray
 struct TriTester
 {
+  const orc_scene& sc;
   bool wt;
   WtRay R;
-  TriTester(const orc_scene& s, V3 d) : wt(s.watertight != 0), R(wt ? wt_prepare(d) : WtRay{2, 0.0f, 0.0f, 0.0f}) {}
+  uint32_t seed;
+  bool stage;  // false: this query has no any-hit stage (the G-buffer's primary rays stand for a raster pass)
+  TriTester(const orc_scene& s, V3 d, uint32_t raySeed, bool anyHitStage)
+      : sc(s), wt(s.watertight != 0), R(wt ? wt_prepare(d) : WtRay{2, 0.0f, 0.0f, 0.0f}), seed(raySeed), stage(anyHitStage && s.dissolve != 0)
+  {
+  }
   bool operator()(V3 o, V3 d, const Tri& tr, float& t, float& u, float& v) const
   {
     return wt ? isect_tri_wt(R, o, tr, t, u, v) : isect_tri(o, d, tr, t, u, v);
+  }
+  // true: the candidate hit on `tr` is ignored (ignoreIntersectionEXT)
+  bool ignores(const Tri& tr) const
+  {
+    if(!stage)
+      return false;
+    const float alpha = sc.mats[(size_t)std::max(0, sc.pm[sc.inst[tr.inst].primMesh].materialIndex)].pbrBaseColorFactor[3];
+    return alpha < 1.0f && dissolveIgnores(alpha, tr.gid, seed);
   }
 };
 
@@ -431,7 +460,11 @@ inline void consider(const TriTester& test, const Tri& tr, V3 o, V3 d, float tmi
     return;
   if(!(t > tmin))
     return;
-  if(t < best.t || (t == best.t && (int32_t)tr.gid < best.tri))
+  if(!(t < best.t || (t == best.t && (int32_t)tr.gid < best.tri)))
+    return;
+  if(test.ignores(tr))
+    return;
+  if(true)
   {
     best.t = t; best.u = u; best.v = v; best.tri = (int32_t)tr.gid;
   }
@@ -449,39 +482,39 @@ inline void tapRay(V3 o, V3 d, float tmin, float tmax, bool any)
   }
 }
 
-Hit closest_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+Hit closest_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c, uint32_t raySeed = 0, bool anyHitStage = true)
 {
   tapRay(o, d, tmin, tmax, false);
   Hit best{tmax, 0, 0, -1};
-  const TriTester test(s, d);
+  const TriTester test(s, d, raySeed, anyHitStage);
   // tmax exclusive: a hit needs t < tmax; emulate by starting best.t = tmax with tri = -1
   // (tie rule "gid < -1" never holds, so t == tmax is rejected).
   for(const Tri& tr : s.tris)
     consider(test, tr, o, d, tmin, best, c);
   return best;
 }
-bool any_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+bool any_brute(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c, uint32_t raySeed = 0, bool anyHitStage = true)
 {
   tapRay(o, d, tmin, tmax, true);
-  const TriTester test(s, d);
+  const TriTester test(s, d, raySeed, anyHitStage);
   for(const Tri& tr : s.tris)
   {
     float t, u, v;
     c.tris_tested++;
-    if(test(o, d, tr, t, u, v) && t > tmin && t < tmax)
+    if(test(o, d, tr, t, u, v) && t > tmin && t < tmax && !test.ignores(tr))
       return true;
   }
   return false;
 }
 
-Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c, uint32_t raySeed = 0, bool anyHitStage = true)
 {
   tapRay(o, d, tmin, tmax, false);
   Hit best{tmax, 0, 0, -1};
   if(s.tris.empty())
     return best;
   RayInv r{o, v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z))};
-  const TriTester test(s, d);
+  const TriTester test(s, d, raySeed, anyHitStage);
   int32_t stack[256];
   int sp = 0;
   int32_t cur = s.rootIsLeaf ? ~0 : 0;
@@ -516,13 +549,13 @@ Hit closest_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters
   }
   return best;
 }
-bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c)
+bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c, uint32_t raySeed = 0, bool anyHitStage = true)
 {
   tapRay(o, d, tmin, tmax, true);
   if(s.tris.empty())
     return false;
   RayInv r{o, v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z))};
-  const TriTester test(s, d);
+  const TriTester test(s, d, raySeed, anyHitStage);
   int32_t stack[256];
   int sp = 0;
   int32_t cur = s.rootIsLeaf ? ~0 : 0;
@@ -535,7 +568,7 @@ bool any_bvh(const orc_scene& s, V3 o, V3 d, float tmin, float tmax, Counters& c
       {
         float t, u, v;
         c.tris_tested++;
-        if(test(o, d, s.tris[s.triOrder[lf.first + k]], t, u, v) && t > tmin && t < tmax)
+        if(test(o, d, s.tris[s.triOrder[lf.first + k]], t, u, v) && t > tmin && t < tmax && !test.ignores(s.tris[s.triOrder[lf.first + k]]))
           return true;
       }
     }
@@ -1201,7 +1234,7 @@ void rayGen(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms&
     {
       c.rays_closest++;
       V3 rd = prd.rayDirection;
-      Hit h = useBvh ? closest_bvh(s, prd.rayOrigin, rd, tMin, tMax, c) : closest_brute(s, prd.rayOrigin, rd, tMin, tMax, c);
+      Hit h = useBvh ? closest_bvh(s, prd.rayOrigin, rd, tMin, tMax, c, prd.seed) : closest_brute(s, prd.rayOrigin, rd, tMin, tMax, c, prd.seed);
       if(log)
       {
         float ray[8] = {-2.0f, prd.rayOrigin.x, prd.rayOrigin.y, prd.rayOrigin.z, rd.x, rd.y, rd.z, tMax};
@@ -1218,8 +1251,8 @@ void rayGen(const orc_scene& s, const PushConstantRay& pc, const GlobalUniforms&
       {
         c.rays_shadow++;
         float smax = prd.lightDist - 0.1f;
-        shadowHit = useBvh ? any_bvh(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c)
-                           : any_brute(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c);
+        shadowHit = useBvh ? any_bvh(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c, prd.seed)
+                           : any_brute(s, prd.rayOrigin, prd.shadowRayDir, tMin, smax, c, prd.seed);
         if(log)
         {
           float ray[8] = {-3.0f, prd.rayOrigin.x, prd.rayOrigin.y, prd.rayOrigin.z, prd.shadowRayDir.x, prd.shadowRayDir.y, prd.shadowRayDir.z, smax};
@@ -1394,7 +1427,8 @@ void gbufferPixel(const orc_scene& s, const float clearColor[4], int lightsCount
   mat4MulVec4(uni.viewInverse, t4, direction);
   const V3 org = v3(origin[0], origin[1], origin[2]), dir = v3(direction[0], direction[1], direction[2]);
   c.rays_closest++;
-  const Hit h = useBvh ? closest_bvh(s, org, dir, 0.001f, 10000.0f, c) : closest_brute(s, org, dir, 0.001f, 10000.0f, c);
+  // (the raster pass this ray stands for has no any-hit stage and no alpha test: every triangle is opaque here)
+  const Hit h = useBvh ? closest_bvh(s, org, dir, 0.001f, 10000.0f, c, 0u, false) : closest_brute(s, org, dir, 0.001f, 10000.0f, c, 0u, false);
   if(h.tri < 0)
     return;
   const Tri& tr = s.tris[h.tri];
@@ -1533,7 +1567,7 @@ void hybridPixel(const orc_scene& s, const PushConstantRay& pc, const GlobalUnif
   const float roughness = g.rough[0], metalness = g.rough[1];
   auto anyHit = [&](V3 o, V3 d, float tmin, float tmax) {
     c.rays_shadow++;
-    return useBvh ? any_bvh(s, o, d, tmin, tmax, c) : any_brute(s, o, d, tmin, tmax, c);
+    return useBvh ? any_bvh(s, o, d, tmin, tmax, c, prd.seed) : any_brute(s, o, d, tmin, tmax, c, prd.seed);
   };
   if(pc.useShadows == 1)  // rgen:81-131
   {
@@ -1599,7 +1633,7 @@ void hybridPixel(const orc_scene& s, const PushConstantRay& pc, const GlobalUnif
     {
       c.rays_closest++;
       const V3 rd = prd.rayDirection;
-      const Hit h = useBvh ? closest_bvh(s, prd.rayOrigin, rd, tMin, tMax, c) : closest_brute(s, prd.rayOrigin, rd, tMin, tMax, c);
+      const Hit h = useBvh ? closest_bvh(s, prd.rayOrigin, rd, tMin, tMax, c, prd.seed) : closest_brute(s, prd.rayOrigin, rd, tMin, tMax, c, prd.seed);
       if(h.tri >= 0)
         closestHitShader(cx, pc, h, rd, prd);
       else
@@ -2016,6 +2050,8 @@ int orc_hybrid_rows_nrd(const orc_scene* s, const PushConstantRay* pc, const Glo
 /* Ray/triangle test of every later query on this scene: 0 = Moeller-Trumbore (default), 1 = watertight (VKRT_OPT_WATERTIGHT).  The
  * tree need not be rebuilt (its boxes bound both vertex forms). */
 void orc_set_watertight(orc_scene* s, int on) { s->watertight = on ? 1 : 0; }
+/* Any-hit alpha / dissolve stage of every later query (VKRT_OPT_ANYHIT_DISSOLVE): 0 = all geometry opaque (default, as the reference runs). */
+void orc_set_dissolve(orc_scene* s, int on) { s->dissolve = on ? 1 : 0; }
 
 /* The rays raytraceHybrid.rgen traces for ONE pixel, in order (9 floats each: o.xyz, d.xyz, tmin, tmax, any-hit flag); gpix = the
  * pixel's G-buffer texels (color4, position4, normal4, rough2).  Returns the number of floats the full log has. */

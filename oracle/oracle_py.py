@@ -72,6 +72,7 @@ def lib():
         L.orc_sample_texture_grad.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_set_gbuffer_mips.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_watertight.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_dissolve.argtypes = [C.c_void_p, C.c_int]
         L.orc_texture_levels.argtypes = [C.c_void_p, C.c_int]
         L.orc_texture_levels.restype = C.c_uint32
         L.orc_texture_level.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -232,6 +233,10 @@ class OracleScene:
     def set_watertight(self, on):
         """ray/triangle test of every later query: False = Moeller-Trumbore (default), True = the watertight test (VKRT_OPT_WATERTIGHT)"""
         lib().orc_set_watertight(self._h, 1 if on else 0)
+
+    def set_dissolve(self, on):
+        """any-hit alpha / dissolve stage (VKRT_OPT_ANYHIT_DISSOLVE): False = all geometry opaque (default)"""
+        lib().orc_set_dissolve(self._h, 1 if on else 0)
 
     def set_gbuffer_mips(self, on):
         lib().orc_set_gbuffer_mips(self._h, 1 if on else 0)

@@ -161,6 +161,39 @@ def test_config4_4k_eight_shards_reassemble_to_the_unsharded_image(atrium_full):
     assert mismatch_fraction(full[rows], ref) < 1e-4 and rmse(full[rows], ref) < RMSE_TOL
 
 
+# ---- C3 on Sponza-like tessellation ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("build", ["ploc", "sah"])
+def test_config3_on_nonuniform_tessellation_rows_match_oracle(build):
+    """The bench frame (1920x1080, 16 spp, depth 8) on the atrium variant with artist-like tessellation: room-sized wall and floor
+    triangles, 15 m x 3 cm moulding needles (aspect 500 : 1), strip drapery with a nearly coincident second layer, dense small
+    detail.  Big and thin triangles overlap hundreds of small boxes -- hard on the builders, and on the triangle test's margins."""
+    import atrium
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat, info = atrium.build_atrium(262144, seed=1, with_textures=True, variant="nonuniform")
+    assert info["triangles"] == 262144
+    W, H = 1920, 1080
+    cam = default_camera(W, H, **atrium.DEFAULT_CAMERA)
+    pc = make_push_constants(samples=16, depth=8, frame=0, lights_count=len(flat.lights))
+    rows = np.unique(np.linspace(0, H - 1, 16).astype(np.uint32))
+    if "ref" not in _NONUNIFORM_MEMO:
+        _NONUNIFORM_MEMO["ref"] = oracle_py.OracleScene(flat).render(pc, cam, W, H, seed=0, rows=rows, threads=THREADS)[0]
+    ref = _NONUNIFORM_MEMO["ref"]
+    r = Renderer(flat, device=0, build=build)
+    chk = r.check_accel()
+    assert chk["triangles_missing"] == 0 and chk["triangles_repeated"] == 0 and chk["box_violations"] == 0 and chk["bad_references"] == 0, chk
+    got = r.pathtrace(pc, cam, W, H, seed=0).cpu().numpy()[rows]
+    assert r.counters()["traversal_faults"] == 0
+    r.close()
+    assert rmse(got, ref) < RMSE_TOL
+    assert mismatch_fraction(got, ref) < 1e-4
+
+
+_NONUNIFORM_MEMO = {}
+
+
 # ---- C5 ------------------------------------------------------------------------------------------------------------
 def test_config5_hybrid_1080p_full_atrium(atrium_full):
     """Hybrid frame (ray-cast G-buffer, shadows + AO + GI depth 8, two accumulated frames, post) at 1920x1080 on the

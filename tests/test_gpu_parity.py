@@ -931,3 +931,62 @@ def test_skipping_dead_shadow_rays_changes_no_pixel(cornell_flat, atrium_small, 
     assert c1["rays_shadow"] < c0["rays_shadow"]
     if scene == "atrium":
         assert c1["rays_shadow"] < 0.9 * c0["rays_shadow"]  # an interior lit by eight point lights: a good part of the picks face away
+
+
+@pytest.mark.parametrize("kind,options", [("ploc", {}), ("sah", {}), ("lbvh", {2: 0}), ("ploc", {1: 0}), ("ploc", {5: 0}), ("ploc", {10: 1})])
+def test_anyhit_dissolve_stage_matches_the_oracle(cornell_flat, kind, options):
+    """VKRT_OPT_ANYHIT_DISSOLVE (raytrace_rahit_todo.glsl:23-37 on the glTF material's alpha): translucent, nearly transparent (the
+    Cornell file's own material 7, alpha 0.05) and invisible (alpha 0) materials; rays, the path tracer over progressive frames and
+    the hybrid passes bit for bit against the oracle, for the wavefront pipeline (with / without work sharing), the megakernel,
+    both node layouts and together with the watertight test (option 10)."""
+    import copy
+
+    import oracle_py
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat = copy.deepcopy(cornell_flat)
+    for m, a in {1: 0.5, 3: 0.25, 4: 0.0, 6: 0.9}.items():
+        flat.materials["pbrBaseColorFactor"][m, 3] = a
+    orc = oracle_py.OracleScene(flat)
+    orc.set_dissolve(True)
+    orc.set_watertight(options.get(abi.VKRT_OPT_WATERTIGHT, 0) == 1)
+    r = Renderer(flat, device=0, build=kind, options={**options, abi.VKRT_OPT_ANYHIT_DISSOLVE: 1})
+    o, d = _ray_set(30000, 31)
+    t0, u0, v0, g0, _ = orc.trace_rays(o, d, use_bvh=False)
+    t1, u1, v1, g1 = r.trace_rays(o, d)
+    assert np.array_equal(g0, g1)
+    hit = g0 >= 0
+    assert np.array_equal(t0[hit].view(np.uint32), t1[hit].view(np.uint32))
+    _, _, _, a0, _ = orc.trace_rays(o, d, tmin=0.001, tmax=3.0, any_hit=True, use_bvh=False)
+    _, _, _, a1 = r.trace_rays(o, d, tmin=0.001, tmax=3.0, any_hit=True)
+    assert np.array_equal(a0, a1)
+    W, H = 200, 150
+    cam = default_camera(W, H)
+    ref = img = None
+    r.reset_counters()
+    for f in range(2):
+        pc = make_push_constants(samples=3, depth=6, frame=f, lights_count=1)
+        ref, cref = orc.render(pc, cam, W, H, seed=70 + f, image=ref)
+        img = r.pathtrace(pc, cam, W, H, seed=70 + f, image=img)
+    got = img.cpu().numpy()
+    assert mismatch_fraction(got, ref) < 1e-4 and rmse(got, ref) < RMSE_TOL
+    # the stage changes the picture (opaque rendering of the same scene differs in many pixels)
+    orc.set_dissolve(False)
+    opaque, _ = orc.render(make_push_constants(samples=3, depth=6, frame=0, lights_count=1), cam, W, H, seed=70)
+    orc.set_dissolve(True)
+    first, _ = orc.render(make_push_constants(samples=3, depth=6, frame=0, lights_count=1), cam, W, H, seed=70)
+    assert mismatch_fraction(first, opaque) > 0.05
+    # hybrid passes: the G-buffer is opaque (a raster pass has no any-hit stage), the traced part sees the stage
+    g = r.gbuffer_raycast(cam, W, H, lights_count=1)
+    go = orc.gbuffer(cam, W, H, lights_count=1)
+    for k in go:
+        assert mismatch_fraction(g[k].cpu().numpy(), go[k]) < 1e-3, k
+    pc = make_push_constants(samples=1, depth=5, frame=0, lights_count=1)
+    pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+    acc = r.hybrid_trace(pc, cam, W, H, g, seed=8).cpu().numpy()
+    ao, _ = orc.hybrid(pc, cam, W, H, go, seed=8)
+    assert mismatch_fraction(acc, ao) < 1e-3 and rmse(acc, ao) < RMSE_TOL
+    assert r.counters()["traversal_faults"] == 0
+    r.close()

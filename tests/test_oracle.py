@@ -306,3 +306,81 @@ def test_watertight_test_has_no_leaks_along_shared_edges_and_vertices():
     assert (g_wt < 0).sum() == 0, int((g_wt < 0).sum())
     assert np.array_equal(g_wt, g_wt_tree)
     assert (g_mt < 0).sum() > 0  # the default test does leak on these rays
+
+
+# ---- any-hit alpha / dissolve stage (VKRT_OPT_ANYHIT_DISSOLVE; raytrace_rahit_todo.glsl:23-37, inert in the reference) ----------------
+def _cornell_with_alpha(cornell_flat, alphas):
+    import copy
+
+    flat = copy.deepcopy(cornell_flat)
+    for m, a in alphas.items():
+        flat.materials["pbrBaseColorFactor"][m, 3] = a
+    return flat
+
+
+def test_dissolve_stage_is_inert_for_opaque_materials_and_tree_independent(cornell_flat):
+    W, H = 96, 64
+    cam = default_camera(W, H)
+    pc = make_push_constants(samples=2, depth=4, frame=0, lights_count=1)
+    assert abs(float(cornell_flat.materials["pbrBaseColorFactor"][7, 3]) - 0.05) < 1e-6  # the asset itself carries one non-opaque material
+    orc = oracle_py.OracleScene(_cornell_with_alpha(cornell_flat, {7: 1.0}))
+    base, c0 = orc.render(pc, cam, W, H, seed=5)
+    orc.set_dissolve(True)
+    same, c1 = orc.render(pc, cam, W, H, seed=5)
+    assert np.array_equal(base.view(np.uint32), same.view(np.uint32)) and c0["rays_shadow"] == c1["rays_shadow"]  # every alpha is 1
+    # materials 0..8 of the Cornell file; make three of them translucent and one invisible (7 keeps the file's 0.05)
+    flat = _cornell_with_alpha(cornell_flat, {1: 0.5, 3: 0.25, 4: 0.0, 6: 0.9})
+    o2 = oracle_py.OracleScene(flat)
+    opaque, _ = o2.render(pc, cam, W, H, seed=5)
+    assert np.array_equal(opaque.view(np.uint32), base.view(np.uint32))  # stage off: alpha is not looked at
+    o2.set_dissolve(True)
+    tree, ct = o2.render(pc, cam, W, H, seed=5)
+    brute, cb = o2.render(pc, cam, W, H, seed=5, use_bvh=False)
+    assert np.array_equal(tree.view(np.uint32), brute.view(np.uint32)) and ct["rays_closest"] == cb["rays_closest"]
+    assert np.mean(np.any(tree.view(np.uint32) != base.view(np.uint32), axis=-1)) > 0.05  # and it does change the picture
+
+
+def test_dissolve_stage_passes_the_expected_fraction_of_rays():
+    """A screen of material alpha in front of a backdrop: the fraction of rays that reach the backdrop is 1 - alpha (each ray decides per
+    triangle from rnd(tea(triangle id, seed)); seed 0 rays differ by triangle only, so a finely tessellated screen is used)."""
+    from vkrt_amd.flat_scene import LIGHT_DTYPE, MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, FlatScene
+
+    g = 40
+    xs = np.linspace(-1, 1, g + 1, dtype=np.float32)
+    gx, gy = np.meshgrid(xs, xs)
+    screen = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size, np.float32)], -1)
+    idx = []
+    for j in range(g):
+        for i in range(g):
+            a = j * (g + 1) + i
+            idx += [a, a + 1, a + g + 1, a + 1, a + g + 2, a + g + 1]
+    back = np.array([[-3, -3, -1], [3, -3, -1], [3, 3, -1], [-3, 3, -1]], np.float32)
+    pos = np.concatenate([screen, back]).astype(np.float32)
+    V = pos.shape[0]
+    idx_all = np.concatenate([np.array(idx, np.uint32), np.array([0, 1, 2, 0, 2, 3], np.uint32)])
+    pm = np.zeros(2, PRIM_DTYPE)
+    pm[0] = (0, len(idx), 0, screen.shape[0], 0)
+    pm[1] = (len(idx), 6, screen.shape[0], 4, 1)
+    nodes = np.zeros(2, NODE_DTYPE)
+    for k in range(2):
+        nodes[k]["worldMatrix"] = np.eye(4, dtype=np.float32).ravel(); nodes[k]["primMesh"] = k
+    lights = np.zeros(1, LIGHT_DTYPE); lights[0] = ((0.0, 0.0, 5.0), (1, 1, 1), 10.0, 0)
+    rng = np.random.default_rng(4)
+    n = 20000
+    o = np.concatenate([rng.uniform(-0.95, 0.95, (n, 2)), np.full((n, 1), 2.0)], 1).astype(np.float32)
+    d = np.tile(np.array([[0, 0, -1]], np.float32), (n, 1))
+    for alpha in (0.0, 0.3, 0.75, 1.0):
+        mats = np.zeros(2, MAT_DTYPE)
+        for m in mats:
+            m["pbrBaseColorFactor"] = [0.8, 0.8, 0.8, 1.0]
+            m["pbrBaseColorTexture"] = m["metallicRoughnessTexture"] = m["normalTexture"] = m["emissiveTexture"] = -1
+        mats[0]["pbrBaseColorFactor"][3] = alpha
+        flat = FlatScene(pos, np.tile(np.array([0, 0, 1], np.float32), (V, 1)), np.tile(np.array([1, 0, 0, 1], np.float32), (V, 1)), np.zeros((V, 2), np.float32),
+                         idx_all, pm, mats, lights, nodes, [])
+        orc = oracle_py.OracleScene(flat)
+        orc.set_dissolve(True)
+        t, _, _, gid, _ = orc.trace_rays(o, d)
+        through = float(np.mean(gid >= len(idx) // 3))  # hit the backdrop (its two triangles come last)
+        assert abs(through - (1.0 - alpha)) < 0.03, (alpha, through)
+        _, _, _, anyh, _ = orc.trace_rays(o, d, tmin=0.001, tmax=2.5, any_hit=True)  # shadow-type query that ends before the backdrop
+        assert abs(float(np.mean(anyh < 0)) - (1.0 - alpha)) < 0.03

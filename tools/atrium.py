@@ -300,7 +300,12 @@ def build_atrium(target_triangles=262144, seed=1, with_textures=True, variant=No
     """Returns (FlatScene, info dict) with exactly `target_triangles` instanced triangles
     (the tessellation scale is calibrated downwards, then small clutter tops the count up).
     variant="emissive_mixed_lights": same geometry; seven materials get an sRGB emissive texture and the file carries
-    five lights (2 point, 2 directional, 1 spot) instead of relying on the fallback lights."""
+    five lights (2 point, 2 directional, 1 spot) instead of relying on the fallback lights.
+    variant="nonuniform": the tessellation of an artist-made scene like the real Sponza instead of uniform grids: floor, walls
+    and slabs are a handful of room-sized triangles; 3-cm mouldings, cornices and pilaster edges run the length of the building
+    as needle triangles (aspect up to 500 : 1); the drapery is long thin strips with a second, nearly coincident layer; banners
+    hang as 20-cm ribbons; the triangle budget goes into dense small detail instead (fluted columns, statues' worth of blobs).
+    The boxes of the big and the thin triangles overlap hundreds of small ones: the case spatial splits exist for."""
     d = float(np.sqrt(target_triangles / 360000.0))
     for _ in range(8):
         flat, info = _build_atrium(target_triangles, seed, with_textures, d, variant)
@@ -325,18 +330,40 @@ def _build_atrium(target_triangles, seed, with_textures, d, variant=None):
     X0, X1, Y1, Z0, Z1 = -15.0, 15.0, 12.0, -9.0, 9.0
     GZ = 4.6       # colonnade line |z|
     H1 = 5.4       # storey height
+    assert variant in (None, "emissive_mixed_lights", "nonuniform"), variant
+    coarse = variant == "nonuniform"
+    def big(x):  # grid resolution of the large flat surfaces: a few room-sized triangles in the non-uniform variant
+        return 1 if coarse else n_(x)
     # floor + roof over the galleries + outer walls (large polygons, coarse grids)
-    place(add_mesh(_quad((X0, 0, Z1), (X1 - X0, 0, 0), (0, 0, Z0 - Z1), n_(60), n_(36), (15, 9)), 0), np.eye(4))
+    place(add_mesh(_quad((X0, 0, Z1), (X1 - X0, 0, 0), (0, 0, Z0 - Z1), 2 if coarse else n_(60), 2 if coarse else n_(36), (15, 9)), 0), np.eye(4))
     for zs in (-1, 1):
         z_in, z_out = zs * GZ, zs * Z1
         zl, zh = min(z_in, z_out), max(z_in, z_out)
-        place(add_mesh(_box((X0, H1, zl), (X1, H1 + 0.5, zh), (n_(30), 1, n_(6)), uv=0.5), 1), np.eye(4))           # gallery slab
-        place(add_mesh(_box((X0, 2 * H1 + 0.6, zl), (X1, Y1, zh), (n_(30), 1, n_(6)), uv=0.5), 2), np.eye(4))        # roof slab
-        wall = _quad((X0, 0, zs * Z1), (X1 - X0, 0, 0), (0, Y1, 0), n_(40), n_(16), (10, 4), flip=(zs > 0))
+        place(add_mesh(_box((X0, H1, zl), (X1, H1 + 0.5, zh), (big(30), 1, big(6)), uv=0.5), 1), np.eye(4))           # gallery slab
+        place(add_mesh(_box((X0, 2 * H1 + 0.6, zl), (X1, Y1, zh), (big(30), 1, big(6)), uv=0.5), 2), np.eye(4))        # roof slab
+        wall = _quad((X0, 0, zs * Z1), (X1 - X0, 0, 0), (0, Y1, 0), big(40), big(16), (10, 4), flip=(zs > 0))
         place(add_mesh(wall, 3), np.eye(4))
     for xs in (-1, 1):
-        wall = _quad((xs * X1, 0, Z0), (0, 0, Z1 - Z0), (0, Y1, 0), n_(24), n_(16), (6, 4), flip=(xs < 0))
+        wall = _quad((xs * X1, 0, Z0), (0, 0, Z1 - Z0), (0, Y1, 0), big(24), big(16), (6, 4), flip=(xs < 0))
         place(add_mesh(wall, 4), np.eye(4))
+    if coarse:
+        # mouldings and cornices: 3-cm profiles running the length of the building in two pieces (needle triangles, 15 m x 3 cm),
+        # on the outer walls, under the gallery slabs and along the colonnade lines; pilaster edges up the walls
+        trim = add_mesh(_box((0, 0, 0), (X1 - X0, 0.03, 0.03), (2, 1, 1)), 9)
+        for zs in (-1, 1):
+            for y in (0.02, 1.1, 2.9, H1 - 0.05, H1 + 0.52, H1 + 1.6, 2 * H1 + 0.55, Y1 - 0.4):
+                place(trim, _trs((X0, y, zs * (Z1 - 0.04) - 0.015)))
+            for y in (H1 - 0.02, H1 + 0.5, 2 * H1 + 0.58):
+                place(trim, _trs((X0, y, zs * (GZ - 0.55))))
+                place(trim, _trs((X0, y, zs * (GZ + 0.5))))
+        pil = add_mesh(_box((0, 0, 0), (0.04, Y1, 0.04), (1, 2, 1)), 4)
+        for zs in (-1, 1):
+            for x in np.linspace(X0 + 0.8, X1 - 0.8, 14):
+                place(pil, _trs((x, 0, zs * (Z1 - 0.05) - 0.02)))
+        # banners: 20-cm ribbons hanging the height of a storey, long thin triangles in one column
+        for i in range(10):
+            rib = add_mesh(_quad((0, 0, 0), (0.2, 0, 0), (0, -5.0, 0.02 * i), 1, n_(40, 8)), 10 + i % 4)
+            place(rib, _trs((X0 + 3.0 + 2.6 * i, 2 * H1 + 0.4, (-1 if i % 2 else 1) * 3.6), ry=0.3 * i))
 
     # columns: one mesh per storey, instanced (TLAS-instance semantics, hello_vulkan.cpp:1035-1043)
     ncol = 12
@@ -364,9 +391,12 @@ def _build_atrium(target_triangles, seed, with_textures, d, variant=None):
     # hanging cloth (unique meshes: dense, thin, non-planar)
     ncloth = 8
     for i in range(ncloth):
-        cl = add_mesh(_cloth(3.2, 4.2, n_(84, 8), n_(72, 8), rng), 10 + i % 4)
+        # non-uniform variant: the drapery as long thin strips (many columns, few rows) with a second layer 1 cm in front of it
+        cl = add_mesh(_cloth(3.2, 4.2, n_(260, 8), n_(10, 2), rng) if coarse else _cloth(3.2, 4.2, n_(84, 8), n_(72, 8), rng), 10 + i % 4)
         x = X0 + 4.0 + (X1 - X0 - 8.0) * (i // 2) / max(1, ncloth // 2 - 1)
         place(cl, _trs((x, 9.6, (-1 if i % 2 else 1) * 2.1), ry=0.5 * np.pi + 0.1 * i))
+        if coarse:
+            place(cl, _trs((x + 0.01, 9.58, (-1 if i % 2 else 1) * 2.1), ry=0.5 * np.pi + 0.1 * i + 0.004))
 
     # floor clutter: blobs and vases, unique and instanced
     blob_meshes = [add_mesh(_blob(rng.uniform(0.3, 0.6), n_(40, 8), n_(24, 6), rng), 14 + i % 6) for i in range(10)]
@@ -408,7 +438,6 @@ def _build_atrium(target_triangles, seed, with_textures, d, variant=None):
         nd[i]["worldMatrix"] = np.asarray(M, np.float32).T.reshape(-1)
         nd[i]["primMesh"] = mi
     textures = make_textures(rng) if with_textures else []
-    assert variant in (None, "emissive_mixed_lights"), variant
     emis = variant == "emissive_mixed_lights"
     flat = FlatScene(np.concatenate(P), np.concatenate(N), np.concatenate(T), np.concatenate(UV), np.concatenate(IDX),
                      prims, make_materials(rng, with_textures, emissive=emis), mixed_lights() if emis else fallback_lights(), nd, textures)

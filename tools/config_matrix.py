@@ -62,11 +62,54 @@ def timed_frames(r, frames, W, H, cam, spp, depth, lights, shard=None, image=Non
     return image, ms, (c["rays_closest"] + c["rays_shadow"]) / frames
 
 
+def tessellation_block(a, out, lights, threads):
+    # ---- C3 on Sponza-like tessellation: the same atrium with room-sized wall triangles, needle mouldings, strip drapery and dense
+    #      small detail (atrium variant "nonuniform"), beside the uniform one, for the three builders -- is the headline number a
+    #      property of the uniform tessellation?  (1080p, 16 spp, depth 8; nodes / triangles per ray from an instrumented frame)
+    W, H = 1920, 1080
+    cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
+    rows = np.unique(np.linspace(0, H - 1, a.cpu_rows).astype(np.uint32))
+    tess = {}
+    for variant in (None, "nonuniform"):
+        fl, inf = atrium.build_atrium(262144, seed=1, variant=variant)
+        entry = {"triangles": int(inf["triangles"]), "unique_triangles": int(inf["unique_triangles"]), "builders": {}}
+        for kind in ("ploc", "sah", "lbvh"):
+            rr = Renderer(fl, device=0, build=kind)
+            ai = rr.accel_info()
+            timed_frames(rr, 1, W, H, cam, 16, 8, lights)
+            _, ms, rpf = timed_frames(rr, 3, W, H, cam, 16, 8, lights)
+            rr.reset_counters()
+            rr.pathtrace(make_push_constants(samples=16, depth=8, frame=0, lights_count=lights), cam, W, H, seed=0, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL)
+            c = rr.counters()
+            nr = c["rays_closest"] + c["rays_shadow"]
+            entry["builders"][kind] = {"ms_per_frame": ms, "Mrays_s": rpf / ms / 1e3, "rays_per_frame": rpf, "nodes_per_ray": c["nodes_visited"] / nr,
+                                       "tris_per_ray": c["tris_tested"] / nr, "sah_cost": ai["sah_cost"], "nodes": ai["node_count"], "depth": ai["max_depth"],
+                                       "build_ms": ai["build_ms"], "traversal_faults": c["traversal_faults"]}
+            if kind == "ploc" and variant is not None:  # parity of the default tree on the new scene: frame 0 against oracle rows
+                img, _, _ = timed_frames(rr, 1, W, H, cam, 16, 8, lights)
+                ref, _ = oracle_py.OracleScene(fl).render(make_push_constants(samples=16, depth=8, frame=0, lights_count=lights), cam, W, H, seed=0, rows=rows, threads=threads)
+                entry["parity_ploc"] = parity(img.cpu().numpy()[rows], ref)
+            rr.close()
+        tess["uniform" if variant is None else variant] = entry
+        print("C3 tessellation", variant, entry, flush=True)
+    u, n = tess["uniform"]["builders"], tess["nonuniform"]["builders"]
+    tess["nonuniform_over_uniform_Mrays_s"] = {k: n[k]["Mrays_s"] / u[k]["Mrays_s"] for k in u}
+    out["configs"]["C3_tessellation_uniform_vs_sponza_like"] = tess
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "configs.json"))
     ap.add_argument("--cpu-rows", type=int, default=24, help="rows of each image the oracle renders for the parity figure")
+    ap.add_argument("--only-tessellation", action="store_true", help="only the uniform vs Sponza-like tessellation block")
     a = ap.parse_args()
+    if a.only_tessellation:
+        out = {"device": torch.cuda.get_device_name(0), "cpu_threads": min(16, os.cpu_count() or 1), "configs": {}}
+        tessellation_block(a, out, 8, out["cpu_threads"])
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        json.dump(out, open(a.out, "w"), indent=1)
+        print("wrote", a.out)
+        return
     threads = min(16, os.cpu_count() or 1)
     out = {"device": torch.cuda.get_device_name(0), "cpu_threads": threads, "configs": {}}
     cornell = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_flat.npz"))
@@ -168,6 +211,8 @@ def main():
                                                              "display_note": "post.frag's pow() is outside the bit-exact arithmetic profile: GPU and CPU pow differ in the last bits"}
     print("C5", out["configs"]["C5_hybrid_atrium_1080p_shadow_ao_gi"], flush=True)
     r.close()
+
+    tessellation_block(a, out, lights, threads)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print("wrote", a.out)

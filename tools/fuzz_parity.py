@@ -175,6 +175,11 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
     if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SUBFRAMES] = int(rng.integers(1, 5))
     if rng3.random() < 0.2: opts[abi.VKRT_OPT_WATERTIGHT] = 1               # the other triangle test, on both sides
     if rng3.random() < 0.2: opts[abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS] = 1    # must not change a pixel
+    if rng3.random() < 0.15:                                                 # the any-hit alpha / dissolve stage, with non-opaque materials
+        opts[abi.VKRT_OPT_ANYHIT_DISSOLVE] = 1
+        for m in flat.materials:
+            if rng3.random() < 0.6:
+                m["pbrBaseColorFactor"][3] = float(rng3.choice([0.0, 0.05, 0.5, 0.95, float(rng3.random())]))
     opts.update(force_opts or {})
     spp, depth, frames = int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(1, 3))
     L = int(rng.integers(1, len(flat.lights) + 1))
@@ -190,6 +195,7 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
     info = dict(seed=seed, tris=flat.instanced_triangle_count, size=(W, H), kind=kind, opts={int(k): int(v) for k, v in opts.items()}, spp=spp, depth=depth, frames=frames)
     orc = oracle_py.OracleScene(flat)
     orc.set_watertight(opts.get(abi.VKRT_OPT_WATERTIGHT, 0) == 1)
+    orc.set_dissolve(opts.get(abi.VKRT_OPT_ANYHIT_DISSOLVE, 0) == 1)
     r = Renderer(flat, device=0, build=kind, options=opts)
     problems = []
     brute = bool(rng.random() < 0.3) and W * H * spp * frames < 6000  # the oracle's loop over all triangles as the referee

@@ -12,5 +12,5 @@ import json
 for l in open("$OUT"):
     if l.startswith("==="): print(l.strip()); continue
     if not l.startswith("{"): print(l.strip()); continue
-    d=json.loads(l); print("   frame %.3f ms (%s Mrays/s)  traverse %.3f ms  nodes/ray %.2f tris/ray %.2f  node_eff %.3f tri_eff %.3f steps %d/%d"%(d["frame_ms"],d["Mrays_s_frame"],d["traverse_ms"],d["nodes_per_ray"],d["tris_per_ray"],d["node_lane_eff"],d["tri_lane_eff"],d["wave_node_steps"],d["wave_tri_steps"]))
+    d=json.loads(l); print("   frame %.3f ms (%s Mrays/s)  serial: traverse %.3f + rest %.3f ms  nodes/ray %.2f tris/ray %.2f  node_eff %.3f tri_eff %.3f steps %d/%d"%(d["frame_ms"],d["Mrays_s_frame"],d["traverse_ms"],d["total_ms"]-d["traverse_ms"],d["nodes_per_ray"],d["tris_per_ray"],d["node_lane_eff"],d["tri_lane_eff"],d["wave_node_steps"],d["wave_tri_steps"]))
 PY

@@ -290,7 +290,8 @@ void pack_tri_shade(const std::vector<FlatTri>& tris, const std::vector<uint32_t
   }
 }
 
-void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out, bool watertight)
+void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out, bool watertight,
+                    const std::vector<uint8_t>* instDissolves)
 {
   out.resize(order.size() * 12);
   for(size_t s = 0; s < order.size(); s++)
@@ -302,7 +303,9 @@ void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t
     o[0] = t.v0[0]; o[1] = t.v0[1]; o[2] = t.v0[2]; o[3] = r1[0];
     o[4] = r1[1]; o[5] = r1[2]; o[6] = r2[0]; o[7] = r2[1];
     o[8] = r2[2];
-    memcpy(&o[9], &t.gid, 4);
+    // any-hit stage (VKRT_OPT_ANYHIT_DISSOLVE): bit 31 of the id word flags a triangle of a non-opaque material
+    const uint32_t idWord = t.gid | ((instDissolves && t.inst < instDissolves->size() && (*instDissolves)[t.inst]) ? 0x80000000u : 0u);
+    memcpy(&o[9], &idWord, 4);
     memcpy(&o[10], &t.inst, 4);
     memcpy(&o[11], &t.prim, 4);
   }

@@ -39,7 +39,8 @@ void pack_tri_shade(const std::vector<FlatTri>& tris, const std::vector<uint32_t
                     const vkrt_node* nodes, std::vector<uint32_t>& out);
 
 // 48-byte device triangle records in slot order: (v0, e1, e2, ids) for Moeller-Trumbore, (p0, p1, p2, ids) when watertight
-void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out, bool watertight = false);
+void pack_triangles(const std::vector<FlatTri>& tris, const std::vector<uint32_t>& order, std::vector<float>& out, bool watertight = false,
+                    const std::vector<uint8_t>* instDissolves = nullptr);  // instDissolves[inst] != 0: the instance's material is not opaque
 
 }  // namespace vkrt
 

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
     const f3 org = mk3(origin[0], origin[1], origin[2]), dir = primaryDir(P, x, y);
     RayHit hit;
     nClosest = 1;
-    traverse_any<false, WIDE, WT>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
+    traverse_any<false, WIDE, WT ? VKRT_TM_WATERTIGHT : 0>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);  // (a raster pass has no any-hit stage: opaque)
     if(hit.slot >= 0)
     {
       const float4 recq = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
@@ -254,8 +254,9 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
 // One ray of every lane that has one.  SHARE: the 64 lanes of the (one-wave) workgroup walk together and lanes without a ray,
 // or done with theirs, take over pending subtrees of the others (traverse_share.h) -- the call must then be reached by all 64 lanes
 // (workgroup-uniform control flow around it).  Otherwise every lane walks alone.
-template <bool WIDE, bool SHARE, bool WT>
-VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int* shareLds, RayHit& hit, TravCount& tc)
+template <bool WIDE, bool SHARE, int TM>
+VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int* shareLds, RayHit& hit, TravCount& tc,
+                      uint32_t raySeed)
 {
   if(SHARE)
   {
@@ -265,9 +266,9 @@ VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, fl
       o = mk3(0.0f); d = mk3(1.0f, 0.0f, 0.0f); tmax = 0.0f;
     }
     if(anyHit)
-      traverse_wide8_share<false, true, WT>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<false, true, TM>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc, raySeed);
     else
-      traverse_wide8_share<false, false, WT>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<false, false, TM>(sc, valid, o, d, tmin, tmax, stk, shareRes(shareLds), hit, tc, raySeed);
     if(!valid)
       hit.slot = -1;
   }
@@ -275,14 +276,14 @@ VKRT_DEV void hyTrace(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, fl
   {
     hit.slot = -1;
     if(valid)
-      traverse_any<false, WIDE, WT>(sc, o, d, tmin, tmax, anyHit, lds, (int)threadIdx.x, (int)blockDim.x, hit, tc);
+      traverse_any<false, WIDE, TM>(sc, o, d, tmin, tmax, anyHit, lds, (int)threadIdx.x, (int)blockDim.x, hit, tc, raySeed);
   }
 }
 
 // SHARE (the default with the wide layout): one wave per workgroup = one 8x8 tile, every loop and branch around a trace is
 // taken by the whole wave as long as any of its pixels needs it.  The per-pixel sequence of random numbers, rays and float
 // operations is that of rgen either way; tests/test_hybrid.py compares the two instantiations with each other and the oracle.
-template <bool WIDE, bool SHARE, bool WT>
+template <bool WIDE, bool SHARE, int TM>
 __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridParams H)
 {
   extern __shared__ int lds_stack[];
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
       }
       if(anyLane(want))
       {
-        hyTrace<WIDE, SHARE, WT>(sc, want, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, shareLds, hit, tc);
+        hyTrace<WIDE, SHARE, TM>(sc, want, worldPos, L, 0.1f, lightDistance - 0.1f, true, lds_stack, shareLds, hit, tc, prd.seed);
         if(want)
         {
           nShadow++;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
         f3 rayDir = mk3(1.0f, 0.0f, 0.0f);
         if(shaded)
           rayDir = normalize3(samplingHemisphere(prd.seed, tangent, binormal, worldNrm));
-        hyTrace<WIDE, SHARE, WT>(sc, shaded, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, shareLds, hit, tc);
+        hyTrace<WIDE, SHARE, TM>(sc, shaded, worldPos, rayDir, 0.1f, 2.0f, true, lds_stack, shareLds, hit, tc, prd.seed);
         if(shaded)
         {
           nShadow++;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
       while(anyLane(active))
       {
         const f3 rd = prd.rayDirection;
-        hyTrace<WIDE, SHARE, WT>(sc, active, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, shareLds, hit, tc);
+        hyTrace<WIDE, SHARE, TM>(sc, active, prd.rayOrigin, rd, 0.001f, 10000.0f, false, lds_stack, shareLds, hit, tc, prd.seed);
         bool needShadow = false;
         if(active)
         {
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(SHARE ? 64 : HY_BLOCK) void k_hybrid(const HybridPa
         bool shadowHit = false;
         if(anyLane(needShadow))
         {
-          hyTrace<WIDE, SHARE, WT>(sc, needShadow, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, shareLds, hit, tc);
+          hyTrace<WIDE, SHARE, TM>(sc, needShadow, prd.rayOrigin, prd.shadowRayDir, 0.001f, prd.lightDist - 0.1f, true, lds_stack, shareLds, hit, tc, prd.seed);
           if(needShadow)
           {
             nShadow++;
@@ -564,22 +565,30 @@ hipError_t vkrt_launch_hybrid(const TraceParams& P, const float* color, const fl
   const unsigned block = share ? 64u : (unsigned)HY_BLOCK;
   const unsigned blocks = (P.tileCount * 64u + block - 1) / block;
   const size_t lds = (size_t)P.sc.stackCap * block * sizeof(int);
-  const bool wt = P.sc.watertight != 0u;
+  const int tm = (P.sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (P.sc.dissolve ? VKRT_TM_DISSOLVE : 0);
+#define VKRT_HY_LAUNCH(W, S, TM) hipLaunchKernelGGL((k_hybrid<W, S, TM>), dim3(blocks), dim3(block), lds, stream, H)
+#define VKRT_HY_MODES(W, S)                                                                                                            \
+  switch(tm)                                                                                                                            \
+  {                                                                                                                                     \
+    case 0: VKRT_HY_LAUNCH(W, S, 0); break;                                                                                             \
+    case 1: VKRT_HY_LAUNCH(W, S, 1); break;                                                                                             \
+    case 2: VKRT_HY_LAUNCH(W, S, 2); break;                                                                                             \
+    default: VKRT_HY_LAUNCH(W, S, 3); break;                                                                                            \
+  }
   if(share)
   {
-    if(wt) hipLaunchKernelGGL((k_hybrid<true, true, true>), dim3(blocks), dim3(block), lds, stream, H);
-    else hipLaunchKernelGGL((k_hybrid<true, true, false>), dim3(blocks), dim3(block), lds, stream, H);
+    VKRT_HY_MODES(true, true)
   }
   else if(P.sc.layout == 1u)
   {
-    if(wt) hipLaunchKernelGGL((k_hybrid<true, false, true>), dim3(blocks), dim3(block), lds, stream, H);
-    else hipLaunchKernelGGL((k_hybrid<true, false, false>), dim3(blocks), dim3(block), lds, stream, H);
+    VKRT_HY_MODES(true, false)
   }
   else
   {
-    if(wt) hipLaunchKernelGGL((k_hybrid<false, false, true>), dim3(blocks), dim3(block), lds, stream, H);
-    else hipLaunchKernelGGL((k_hybrid<false, false, false>), dim3(blocks), dim3(block), lds, stream, H);
+    VKRT_HY_MODES(false, false)
   }
+#undef VKRT_HY_MODES
+#undef VKRT_HY_LAUNCH
   return hipGetLastError();
 }
 

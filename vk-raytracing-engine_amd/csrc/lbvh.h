@@ -52,6 +52,6 @@ int ploc_cluster_device(uint32_t T, const unsigned* order, const float* triBox, 
 // sc must already hold the uploaded positions / indices / instances.  ploc: cluster (ploc.hip, one triangle per leaf) instead of
 // the Morton radix tree.
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4, bool wantWide = false, bool ploc = false, bool watertight = false);
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4, bool wantWide = false, bool ploc = false, bool watertight = false, bool dissolve = false);
 
 }  // namespace vkrt

@@ -301,8 +301,10 @@ __global__ void k_emit(unsigned kLeaf, int n, const unsigned* order, const float
   atomicAdd(sahAccum, cost);
 }
 
+// materials != NULL (VKRT_OPT_ANYHIT_DISSOLVE): bit 31 of the id word of every triangle whose material has dissolve
+// (pbrBaseColorFactor.a) < 1 is set -- the flag the traversal's any-hit stage looks at (traverse.h anyhit_ignores)
 __global__ void k_pack(unsigned n, const unsigned* order, const float4* triU, float4* outTris, FlatArgs A, const int* instMaterial,
-                       uint4* outShade)
+                       uint4* outShade, const DevMaterial* materials)
 {
   const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
   if(s >= n)
@@ -316,7 +318,14 @@ __global__ void k_pack(unsigned n, const unsigned* order, const float4* triU, fl
   }
   outTris[3 * (size_t)s + 0] = triU[3 * (size_t)g + 0];
   outTris[3 * (size_t)s + 1] = triU[3 * (size_t)g + 1];
-  outTris[3 * (size_t)s + 2] = triU[3 * (size_t)g + 2];
+  float4 c = triU[3 * (size_t)g + 2];
+  if(materials)
+  {
+    const unsigned inst = (unsigned)__float_as_int(c.z);
+    if(materials[max(0, instMaterial[inst])].m.pbrBaseColorFactor[3] < 1.0f)
+      c.y = __int_as_float(__float_as_int(c.y) | (int)0x80000000);
+  }
+  outTris[3 * (size_t)s + 2] = c;
 }
 
 // depth of the emitted tree = max over leaves of the number of emitted ancestors
@@ -614,7 +623,7 @@ struct Temp
   } while(0)
 
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide, bool ploc, bool watertight)
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide, bool ploc, bool watertight, bool dissolve)
 {
   bool topSah = ploc;  // the FAST_TRACE device build re-builds its upper levels with SAH; the radix tree stays the pure fast build
   if(const char* e = getenv("VKRT_TOP_SAH"))  // test hook: force on / off for either builder
@@ -682,7 +691,7 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
   LB_TRY(rocprim::radix_sort_pairs(sortTmp, sortBytes, keysA, keysB, valsA, valsB, (size_t)T, 0, 63, stream));
   const unsigned* order = valsB;
 
-  hipLaunchKernelGGL(k_pack, dim3(G), dim3(B), 0, stream, T, order, (const float4*)triU, (float4*)out.tris, A, (const int*)dMaterial, (uint4*)out.triShade);
+  hipLaunchKernelGGL(k_pack, dim3(G), dim3(B), 0, stream, T, order, (const float4*)triU, (float4*)out.tris, A, (const int*)dMaterial, (uint4*)out.triShade, dissolve ? sc.materials : (const DevMaterial*)nullptr);
   LB_TRY(hipGetLastError());
 
   if(T <= kLeaf)

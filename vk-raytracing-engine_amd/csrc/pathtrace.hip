@@ -22,7 +22,7 @@
 #define VKRT_BLOCK 256
 
 
-template <bool COUNT, int MINW, bool WT>
+template <bool COUNT, int MINW, int TM>
 __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParams P)
 {
   extern __shared__ int lds_stack[];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(VKRT_BLOCK, MINW) void k_pathtrace(const TraceParam
         nClosest++;
       }
       RayHit hit;
-      traverse<COUNT, WT>(P.sc, o, d, tmin, tmax, shadow, stk, VKRT_BLOCK, hit, tc);
+      traverse<COUNT, TM>(P.sc, o, d, tmin, tmax, shadow, stk, VKRT_BLOCK, hit, tc, L.prd.seed);
 
       bool shadowHit = false;
       bool accumulate = true;
@@ -140,16 +140,18 @@ __global__ __launch_bounds__(VKRT_BLOCK) void k_trace_rays(DevScene sc, unsigned
   RayHit hit;
   TravCount tc;
   const f3 ro = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+  // (test hook: the payload seed of these rays is 0)
+  const int tm = (sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (sc.dissolve ? VKRT_TM_DISSOLVE : 0);
+#define VKRT_DBG(W, TM) traverse_any<false, W, TM>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc, 0u)
   if(sc.layout == 1u)
   {
-    if(sc.watertight) traverse_any<false, true, true>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
-    else traverse_any<false, true, false>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+    if(tm == 0) VKRT_DBG(true, 0); else if(tm == 1) VKRT_DBG(true, 1); else if(tm == 2) VKRT_DBG(true, 2); else VKRT_DBG(true, 3);
   }
   else
   {
-    if(sc.watertight) traverse_any<false, false, true>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
-    else traverse_any<false, false, false>(sc, ro, rd, tmin, tmax, anyHit != 0, lds_stack, (int)threadIdx.x, VKRT_BLOCK, hit, tc);
+    if(tm == 0) VKRT_DBG(false, 0); else if(tm == 1) VKRT_DBG(false, 1); else if(tm == 2) VKRT_DBG(false, 2); else VKRT_DBG(false, 3);
   }
+#undef VKRT_DBG
   if(anyHit)
   {
     gid[i] = hit.slot >= 0 ? 0 : -1;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(VKRT_BLOCK) void k_trace_rays(DevScene sc, unsigned
   else
   {
     t[i] = hit.t; u[i] = hit.u; v[i] = hit.v;
-    gid[i] = hit.slot >= 0 ? __float_as_int(sc.tris[hit.slot * VKRT_TRI_QUADS + 2].y) : -1;
+    gid[i] = hit.slot >= 0 ? (__float_as_int(sc.tris[hit.slot * VKRT_TRI_QUADS + 2].y) & 0x7fffffff) : -1;
   }
 }
 
@@ -186,15 +188,20 @@ hipError_t vkrt_launch_pathtrace(const TraceParams& P, unsigned gridBlocks, bool
 {
   const size_t lds = (size_t)P.sc.stackCap * VKRT_BLOCK * sizeof(int);
   const dim3 g(gridBlocks), b(VKRT_BLOCK);
-  if(P.sc.watertight != 0u)
+  const int tm = (P.sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (P.sc.dissolve ? VKRT_TM_DISSOLVE : 0);
+#define VKRT_MEGA(TM)                                                                        \
+  do {                                                                                       \
+    if(count) hipLaunchKernelGGL((k_pathtrace<true, 1, TM>), g, b, lds, stream, P);         \
+    else hipLaunchKernelGGL((k_pathtrace<false, 3, TM>), g, b, lds, stream, P);             \
+  } while(0)
+  switch(tm)
   {
-    if(count) hipLaunchKernelGGL((k_pathtrace<true, 1, true>), g, b, lds, stream, P);
-    else hipLaunchKernelGGL((k_pathtrace<false, 3, true>), g, b, lds, stream, P);
+    case 0: VKRT_MEGA(0); break;
+    case 1: VKRT_MEGA(1); break;
+    case 2: VKRT_MEGA(2); break;
+    default: VKRT_MEGA(3); break;
   }
-  else if(count)
-    hipLaunchKernelGGL((k_pathtrace<true, 1, false>), g, b, lds, stream, P);
-  else
-    hipLaunchKernelGGL((k_pathtrace<false, 3, false>), g, b, lds, stream, P);
+#undef VKRT_MEGA
   return hipGetLastError();
 }
 
@@ -202,7 +209,7 @@ int vkrt_pathtrace_block_size() { return VKRT_BLOCK; }
 
 hipError_t vkrt_pathtrace_occupancy(size_t ldsBytes, int* blocksPerCU)
 {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 3, false>, VKRT_BLOCK, ldsBytes);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, k_pathtrace<false, 3, 0>, VKRT_BLOCK, ldsBytes);
 }
 
 hipError_t vkrt_launch_trace_rays(const DevScene& sc, unsigned n, const float* o, const float* d, float tmin, float tmax, int anyHit,

@@ -132,7 +132,12 @@ VKRT_DEV bool tri_test_wt(const WtRay& R, f3 o, f3 p0, f3 p1, f3 p2, float& t, f
   return true;   // (a NaN anywhere leaves t NaN: every caller's `t > tmin` rejects it)
 }
 
-// Compile-time choice of the test: per-ray constants + one entry point on a 48-byte record (a, b, c).
+// Compile-time "triangle mode" TM of every traversal: bit 0 = the watertight test (VKRT_OPT_WATERTIGHT), bit 1 = the any-hit alpha /
+// dissolve stage (VKRT_OPT_ANYHIT_DISSOLVE).  TM = 0 is the product default and compiles to exactly the code it was before.
+#define VKRT_TM_WATERTIGHT 1
+#define VKRT_TM_DISSOLVE 2
+
+// per-ray constants + one entry point on a 48-byte record (a, b, c)
 template <bool WT> struct TriRay;
 template <> struct TriRay<false>
 {
@@ -152,13 +157,37 @@ template <> struct TriRay<true>
   }
 };
 
+// ---- any-hit alpha / dissolve stage (reference raytrace_rahit_todo.glsl:23-37; never compiled there, all rays gl_RayFlagsOpaqueEXT) ----
+// With VKRT_OPT_ANYHIT_DISSOLVE the builders set bit 31 of the id word of every triangle whose material has dissolve < 1
+// (dissolve = pbrBaseColorFactor.a: the glTF stand-in for the OBJ material's `dissolve`, "illum == 4" = dissolve < 1); a candidate hit
+// on such a triangle is ignored when dissolve == 0 and otherwise when rnd(tea(gid, seed)) > dissolve, seed = the payload's seed when
+// the ray is traced.  (The GLSL draws rnd(prd.seed) per invocation; Vulkan defines neither the order nor the number of any-hit
+// invocations, so the decision is made a pure function of (ray, triangle): results stay independent of the tree and of the
+// schedule.  prd.seed is not advanced.)  Same function in oracle/oracle.cpp (dissolveIgnores).
+template <int TM>
+VKRT_DEV int tri_gid(float idWord)  // the flattened triangle id of a record (bit 31 = dissolve flag when the stage is compiled in)
+{
+  return (TM & VKRT_TM_DISSOLVE) ? (__float_as_int(idWord) & 0x7fffffff) : __float_as_int(idWord);
+}
+template <int TM>
+VKRT_DEV bool anyhit_ignores(const DevScene& sc, unsigned slot, float idWord, uint32_t raySeed)
+{
+  if(!(TM & VKRT_TM_DISSOLVE) || __float_as_int(idWord) >= 0)
+    return false;  // opaque triangle (or the stage is not compiled in)
+  const float alpha = sc.materials[sc.triShade[slot].w].m.pbrBaseColorFactor[3];
+  if(alpha == 0.0f)
+    return true;
+  uint32_t st = tea((uint32_t)(__float_as_int(idWord) & 0x7fffffff), raySeed);
+  return rnd(st) > alpha;
+}
+
 // stk: this lane's LDS stack column (entry k at stk[k * stride]).
-template <bool COUNT, bool WT = false>
+template <bool COUNT, int TM = 0>
 VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* stk, int stride, RayHit& hit,
-                       TravCount& tc)
+                       TravCount& tc, uint32_t raySeed = 0u)
 {
   const f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-  TriRay<WT> tr;
+  TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> tr;
   tr.set(d);
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
@@ -241,7 +270,7 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
           {
             if(anyHit)
             {
-              if(t < tmax)
+              if(t < tmax && !anyhit_ignores<TM>(sc, s, c.y, raySeed))
               {
                 bestSlot = (int)s;
                 bestT = t;
@@ -251,8 +280,8 @@ VKRT_DEV void traverse(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, b
             }
             else
             {
-              const int gid = __float_as_int(c.y);
-              if(t < bestT || (t == bestT && gid < bestGid))
+              const int gid = tri_gid<TM>(c.y);
+              if((t < bestT || (t == bestT && gid < bestGid)) && !anyhit_ignores<TM>(sc, s, c.y, raySeed))
               {
                 bestT = t; bestU = u; bestV = v; bestSlot = (int)s; bestGid = gid;
               }

@@ -21,10 +21,11 @@ VKRT_DEV float ubyte_f32(unsigned w, int k) { return (float)((w >> (8 * k)) & 0x
 // Resumable per-lane traversal state: one w8_iterate() = take the nearest pending child node of the
 // current group, test its 8 children, intersect the triangles the ray's boxes touched, then pop if the
 // group is exhausted.  Used as a plain loop (traverse_wide8) and by the refilling kernel (wavefront.hip).
-template <bool WT>
+template <int TM>
 struct W8State
 {
-  TriRay<WT> tr;
+  TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> tr;
+  uint32_t raySeed;
   f3 o, d, id;
   float tmax, bestT, bestU, bestV;
   int bestSlot, bestGid;
@@ -34,11 +35,12 @@ struct W8State
   bool anyHit;
 };
 
-template <bool WT>
-VKRT_DEV void w8_begin(const DevScene& sc, W8State<WT>& S, f3 o, f3 d, float tmax, bool anyHit)
+template <int TM>
+VKRT_DEV void w8_begin(const DevScene& sc, W8State<TM>& S, f3 o, f3 d, float tmax, bool anyHit, uint32_t raySeed)
 {
   S.o = o; S.d = d;
   S.tr.set(d);
+  S.raySeed = raySeed;
   S.id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   S.tmax = tmax; S.bestT = tmax; S.bestU = 0.0f; S.bestV = 0.0f;
   S.bestSlot = -1; S.bestGid = -1;
@@ -122,8 +124,8 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
 }
 
 // returns true while the ray has more work
-template <bool COUNT, bool ANYHIT, bool WT>
-VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<WT>& S, float tmin, uint2* stk, int stride, TravCount& tc)
+template <bool COUNT, bool ANYHIT, int TM>
+VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<TM>& S, float tmin, uint2* stk, int stride, TravCount& tc)
 {
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
@@ -184,7 +186,7 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<WT>& S, float tmin, uint2* 
       {
         if(ANYHIT)
         {
-          if(t < S.tmax)
+          if(t < S.tmax && !anyhit_ignores<TM>(sc, s, c.y, S.raySeed))
           {
             S.bestSlot = (int)s;
             S.bestT = t;
@@ -193,8 +195,8 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<WT>& S, float tmin, uint2* 
         }
         else
         {
-          const int gid = __float_as_int(c.y);
-          if(t < S.bestT || (t == S.bestT && gid < S.bestGid))
+          const int gid = tri_gid<TM>(c.y);
+          if((t < S.bestT || (t == S.bestT && gid < S.bestGid)) && !anyhit_ignores<TM>(sc, s, c.y, S.raySeed))
           {
             S.bestT = t; S.bestU = u; S.bestV = v; S.bestSlot = (int)s; S.bestGid = gid;
           }
@@ -221,10 +223,11 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<WT>& S, float tmin, uint2* 
 // hold one, or when no lane has node work left.  A second group arriving while T is still pending is parked on the
 // top end of the lane's stack column (at most VKRT_W8_MAX_POSTPONED per lane, else tested at once).
 // The result does not depend on the order (closest = smallest t, ties -> smallest triangle id; any = exists).
-template <bool COUNT, bool ANYHIT, bool WT>
-VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, uint2* stk, int stride, RayHit& hit, TravCount& tc)
+template <bool COUNT, bool ANYHIT, int TM>
+VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, uint2* stk, int stride, RayHit& hit, TravCount& tc,
+                                      uint32_t raySeed)
 {
-  TriRay<WT> tr;
+  TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> tr;
   tr.set(d);
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
@@ -259,7 +262,7 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
     {
       if(ANYHIT)
       {
-        if(t < tmax)
+        if(t < tmax && !anyhit_ignores<TM>(sc, s, c.y, raySeed))
         {
           bestSlot = (int)s; bestT = t;
           return true;
@@ -267,8 +270,8 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
       }
       else
       {
-        const int gid = __float_as_int(c.y);
-        if(t < bestT || (t == bestT && gid < bestGid))
+        const int gid = tri_gid<TM>(c.y);
+        if((t < bestT || (t == bestT && gid < bestGid)) && !anyhit_ignores<TM>(sc, s, c.y, raySeed))
         {
           bestT = t; bestU = u; bestV = v; bestSlot = (int)s; bestGid = gid;
         }
@@ -352,28 +355,28 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
   hit.t = bestT; hit.u = bestU; hit.v = bestV; hit.slot = bestSlot;
 }
 
-template <bool COUNT, bool WT = false>
+template <bool COUNT, int TM = 0>
 VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, uint2* stk, int stride, RayHit& hit,
-                             TravCount& tc)
+                             TravCount& tc, uint32_t raySeed = 0u)
 {
   if(sc.triThreshold != 0u)  // launch-uniform
   {
     if(anyHit)
-      traverse_wide8_postpone<COUNT, true, WT>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
+      traverse_wide8_postpone<COUNT, true, TM>(sc, o, d, tmin, tmax, stk, stride, hit, tc, raySeed);
     else
-      traverse_wide8_postpone<COUNT, false, WT>(sc, o, d, tmin, tmax, stk, stride, hit, tc);
+      traverse_wide8_postpone<COUNT, false, TM>(sc, o, d, tmin, tmax, stk, stride, hit, tc, raySeed);
     return;
   }
-  W8State<WT> S;
-  w8_begin(sc, S, o, d, tmax, anyHit);
+  W8State<TM> S;
+  w8_begin(sc, S, o, d, tmax, anyHit, raySeed);
   if(S.G.y != 0u)
   {
     if(anyHit)  // workgroup-uniform in the wavefront kernels: two specialised loops, no per-triangle branch
-      while(w8_iterate<COUNT, true, WT>(sc, S, tmin, stk, stride, tc))
+      while(w8_iterate<COUNT, true, TM>(sc, S, tmin, stk, stride, tc))
       {
       }
     else
-      while(w8_iterate<COUNT, false, WT>(sc, S, tmin, stk, stride, tc))
+      while(w8_iterate<COUNT, false, TM>(sc, S, tmin, stk, stride, tc))
       {
       }
   }
@@ -381,12 +384,12 @@ VKRT_DEV void traverse_wide8(const DevScene& sc, f3 o, f3 d, float tmin, float t
 }
 
 // layout dispatch used by the kernels: stkWords = this lane's LDS stack column (4-byte words, stride in words)
-template <bool COUNT, bool WIDE, bool WT = false>
+template <bool COUNT, bool WIDE, int TM = 0>
 VKRT_DEV void traverse_any(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, bool anyHit, int* lds, int tid, int block, RayHit& hit,
-                           TravCount& tc)
+                           TravCount& tc, uint32_t raySeed = 0u)
 {
   if(WIDE)
-    traverse_wide8<COUNT, WT>(sc, o, d, tmin, tmax, anyHit, ((uint2*)lds) + tid, block, hit, tc);
+    traverse_wide8<COUNT, TM>(sc, o, d, tmin, tmax, anyHit, ((uint2*)lds) + tid, block, hit, tc, raySeed);
   else
-    traverse<COUNT, WT>(sc, o, d, tmin, tmax, anyHit, lds + tid, block, hit, tc);
+    traverse<COUNT, TM>(sc, o, d, tmin, tmax, anyHit, lds + tid, block, hit, tc, raySeed);
 }

@@ -61,6 +61,7 @@ struct vkrt_scene
   std::vector<vkrt_prim_mesh> primMeshes;
   std::vector<vkrt_node> nodes;
   uint32_t lightCount = 0, materialCount = 0;
+  std::vector<float> materialAlpha;  // pbrBaseColorFactor.a per material (the any-hit stage's dissolve), host copy for the host builder
   // device allocations
   std::vector<void*> allocs;
   DevScene dev{};
@@ -81,7 +82,7 @@ struct vkrt_scene
   WfTiming wfTiming{};
   bool wfTimed = false;
   // execution options (include/vkrt.h vkrt_option); index = option id
-  int opt[VKRT_OPT_LAST + 1] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1, 0, 0};
+  int opt[VKRT_OPT_LAST + 1] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1, 0, 0, 0};
   bool wavefront = true;  // execution mode the acceleration structure was built for (opt[VKRT_OPT_MODE] at vkrt_accel_build)
 };
 
@@ -201,7 +202,7 @@ int clampOption(int option, int v)
     case VKRT_OPT_TRI_THRESHOLD: return std::max(0, std::min(65, v));
     case VKRT_OPT_WF_SHARE_PERIOD: return std::max(0, std::min(255, v));
     case VKRT_OPT_WF_SHARE_FLAGS: return v & 1;
-    case VKRT_OPT_GBUFFER_MIPS: case VKRT_OPT_WATERTIGHT: case VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: return v ? 1 : 0;
+    case VKRT_OPT_GBUFFER_MIPS: case VKRT_OPT_WATERTIGHT: case VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: case VKRT_OPT_ANYHIT_DISSOLVE: return v ? 1 : 0;
   }
   return v;
 }
@@ -216,7 +217,8 @@ void optionsFromEnvironment(vkrt_scene* s)
                                                           {"VKRT_WF_SHARE", VKRT_OPT_WF_SHARE}, {"VKRT_TRI_THRESHOLD", VKRT_OPT_TRI_THRESHOLD},
                                                           {"VKRT_WF_SHARE_PERIOD", VKRT_OPT_WF_SHARE_PERIOD}, {"VKRT_WF_SHARE_FLAGS", VKRT_OPT_WF_SHARE_FLAGS},
                                                           {"VKRT_GBUFFER_MIPS", VKRT_OPT_GBUFFER_MIPS}, {"VKRT_WATERTIGHT", VKRT_OPT_WATERTIGHT},
-                                                          {"VKRT_SKIP_DEAD_SHADOW_RAYS", VKRT_OPT_SKIP_DEAD_SHADOW_RAYS}};
+                                                          {"VKRT_SKIP_DEAD_SHADOW_RAYS", VKRT_OPT_SKIP_DEAD_SHADOW_RAYS},
+                                                          {"VKRT_ANYHIT_DISSOLVE", VKRT_OPT_ANYHIT_DISSOLVE}};
   for(const auto& k : ints)
     if((e = getenv(k.name)))
       s->opt[k.option] = clampOption(k.option, atoi(e));
@@ -385,6 +387,7 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   {
     memset(&mats[i], 0, sizeof(DevMaterial));
     mats[i].m = d->materials[i];
+    s->materialAlpha.push_back(d->materials[i].pbrBaseColorFactor[3]);
     const int idx[4] = {mats[i].m.pbrBaseColorTexture, mats[i].m.metallicRoughnessTexture, mats[i].m.normalTexture, mats[i].m.emissiveTexture};
     for(int k = 0; k < 4; k++)
     {
@@ -520,11 +523,21 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   s->info = vkrt_accel_info{};
   s->info.build_flags = wantPloc ? VKRT_BUILD_PLOC_GPU : wantLbvh ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
   s->wavefront = useWavefront(s);
-  const bool watertight = s->opt[VKRT_OPT_WATERTIGHT] != 0;
-  if(watertight && useWavefront(s) && s->opt[VKRT_OPT_WF_TRAV_BLOCK] != 64)
-    return fail(VKRT_ERR_UNSUPPORTED, "VKRT_OPT_WATERTIGHT is built for the default 64-thread traversal workgroups (VKRT_OPT_WF_TRAV_BLOCK = %d)",
-                s->opt[VKRT_OPT_WF_TRAV_BLOCK]);
+  const bool watertight = s->opt[VKRT_OPT_WATERTIGHT] != 0, dissolve = s->opt[VKRT_OPT_ANYHIT_DISSOLVE] != 0;
+  if((watertight || dissolve) && useWavefront(s) && s->opt[VKRT_OPT_WF_TRAV_BLOCK] != 64)
+    return fail(VKRT_ERR_UNSUPPORTED, "VKRT_OPT_WATERTIGHT / VKRT_OPT_ANYHIT_DISSOLVE are built for the default 64-thread traversal workgroups "
+                "(VKRT_OPT_WF_TRAV_BLOCK = %d)", s->opt[VKRT_OPT_WF_TRAV_BLOCK]);
   s->dev.watertight = watertight ? 1u : 0u;
+  s->dev.dissolve = dissolve ? 1u : 0u;
+  // per instance: is its material non-opaque (dissolve = pbrBaseColorFactor.a < 1)?  Only consulted with the any-hit stage on.
+  std::vector<uint8_t> instDissolves;
+  if(dissolve)
+    for(const vkrt_node& n : s->nodes)
+    {
+      const int32_t m = std::max(0, s->primMeshes[(size_t)n.primMesh].materialIndex);
+      instDissolves.push_back(s->materialAlpha[(size_t)m] < 1.0f ? 1 : 0);
+    }
+  const std::vector<uint8_t>* dissolvePtr = dissolve ? &instDissolves : nullptr;
 
   if(wantSah)
   {
@@ -541,14 +554,14 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     if(wide)
     {
       vkrt::build_wide8_host(tris, w8, watertight);
-      vkrt::pack_triangles(tris, w8.triOrder, packed, watertight);
+      vkrt::pack_triangles(tris, w8.triOrder, packed, watertight, dissolvePtr);
       nodeData = w8.nodes.data();
       nodeBytesUsed = w8.nodes.size() * sizeof(uint32_t);
     }
     else
     {
       vkrt::build_sah_host(tris, 4, bvh, watertight);
-      vkrt::pack_triangles(tris, bvh.triOrder, packed, watertight);
+      vkrt::pack_triangles(tris, bvh.triOrder, packed, watertight, dissolvePtr);
       nodeData = bvh.nodes.data();
       nodeBytesUsed = bvh.nodes.size() * sizeof(float);
     }
@@ -600,7 +613,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     // binary tree keeps one triangle per leaf and is collapsed into wide8 nodes by the same SAH-optimal DP as the SAH
     // path -- on the device too (wide_collapse.hip); nothing but four statistics words comes back to the host.
     // VKRT_BUILD_PLOC_GPU: same pipeline with the radix tree replaced by locally-ordered clustering (ploc.hip)
-    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide, wantPloc, watertight);
+    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide, wantPloc, watertight, dissolve);
     if(rc != VKRT_OK)
       return fail(rc, "%s build failed: %s", wantPloc ? "PLOC" : "LBVH", r.error.c_str());
     s->info.triangle_count = r.triCount;
@@ -656,12 +669,13 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
           ft.p2[c] = watertight ? t[6 + c] : t[c] + t[6 + c];
         }
         memcpy(&ft.gid, &t[9], 4); memcpy(&ft.inst, &t[10], 4); memcpy(&ft.prim, &t[11], 4);
+        ft.gid &= 0x7fffffffu;  // (bit 31 = the any-hit stage's flag; pack_triangles sets it again)
       }
       vkrt::BuiltWide8 w8;
       vkrt::collapse_wide8(b2, tris, w8, watertight);
       std::vector<float> packed;
       std::vector<uint32_t> shadeRec;
-      vkrt::pack_triangles(tris, w8.triOrder, packed, watertight);
+      vkrt::pack_triangles(tris, w8.triOrder, packed, watertight, dissolvePtr);
       vkrt::pack_tri_shade(tris, w8.triOrder, s->indices.data(), s->primMeshes.data(), s->nodes.data(), shadeRec);
       HIP_TRY(hipMalloc(&s->accelNodes, std::max<size_t>(w8.nodes.size() * 4, 80)));
       HIP_TRY(hipMalloc(&s->accelTris, std::max<size_t>(packed.size() * 4, 48)));
@@ -826,7 +840,7 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
     HIP_TRY(hipEventRecord(s->evStart, stream));
     WfOptions wo;
     wo.subframes = s->opt[VKRT_OPT_WF_SUBFRAMES];
-    wo.travBlock = s->dev.watertight ? 64 : s->opt[VKRT_OPT_WF_TRAV_BLOCK];  // (watertight kernels exist for the default workgroup only)
+    wo.travBlock = (s->dev.watertight || s->dev.dissolve) ? 64 : s->opt[VKRT_OPT_WF_TRAV_BLOCK];  // (the non-default triangle modes exist for the default workgroup only)
     HIP_TRY(vkrt_launch_wavefront(P, s->wf, wo, count, stream, timing, &s->wfAsync));
     HIP_TRY(hipEventRecord(s->evStop, stream));
     s->timed = true;
@@ -992,7 +1006,7 @@ int hybridImpl(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* c
     HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, vkrt_wf_hybrid_tmp(s->wf), stream));
     HybridGi G{(const float4*)g->color, (const float4*)g->position, (const float4*)g->normal, (const float2*)g->roughMetal, (float4*)accum,
                nrd ? (float4*)nrd->diffRadianceHitDist : nullptr, nrd ? nrd->viewZ : nullptr};
-    HIP_TRY(vkrt_launch_hybrid_gi(P, s->wf, G, s->dev.watertight ? 64u : (unsigned)s->opt[VKRT_OPT_WF_TRAV_BLOCK], stream));
+    HIP_TRY(vkrt_launch_hybrid_gi(P, s->wf, G, (s->dev.watertight || s->dev.dissolve) ? 64u : (unsigned)s->opt[VKRT_OPT_WF_TRAV_BLOCK], stream));
   }
   else
     HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, nullptr, stream));

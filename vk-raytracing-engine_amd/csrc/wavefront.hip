@@ -152,6 +152,11 @@ VKRT_DEV unsigned claimSlots(const WfBuffers& B, int parity, int to, unsigned la
       tot += c;
     }
     w[nw] = tot ? atomicAdd(countOf(B, parity, (int)threadIdx.x), tot) : 0u;
+#if defined(VKRT_EXP) && VKRT_EXP == 3
+    // experiment #87: is the shade stage bound by these returning atomics on three words of one line?  Double them (a dummy
+    // counter on a line of its own per stream type) and see whether the kernel gets slower.
+    if(tot) w[nw] += 0u * atomicAdd(&B.ctrl[16 + 16 * threadIdx.x + (parity & 1)], tot);
+#endif
   }
   __syncthreads();
   if(to < 0)
@@ -230,8 +235,8 @@ VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int ki
 }
 
 // ---- traversal: one thread per queued ray, workgroups homogeneous in ray kind -----------------------------------
-template <bool COUNT, bool WIDE, int TB, bool WT = false>
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WT && WIDE && TB == 64 ? 5 : 1))) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
+template <bool COUNT, bool WIDE, int TB, int TM = 0>
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(TM != 0 && WIDE && TB == 64 ? 5 : 1))) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
 {
   extern __shared__ int lds_stack[];
   const int par = round & 1;
@@ -267,6 +272,10 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WT && WIDE &
     if(kind == WF_K_CLOSEST_P)
       r0.w = 10000.0f;
   }
+  // any-hit stage: the payload's seed when the ray is traced (S0.w: after the shading that produced the ray, raytrace.rgen:64-97)
+  uint32_t raySeed = 0u;
+  if((TM & VKRT_TM_DISSOLVE) && valid)
+    raySeed = __float_as_uint(plane(B, par, type, WF_S0)[qi].w);
   TravCount tc;
   __shared__ int shareLds[VKRT_SHARE_LDS_WORDS];
   RayHit hit;
@@ -275,15 +284,15 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(WT && WIDE &
     // the whole wave walks together: lanes past the end of the stream have no ray of their own but help
     uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
     if(anyHit)
-      traverse_wide8_share<COUNT, true, WT>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<COUNT, true, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
     else
-      traverse_wide8_share<COUNT, false, WT>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc);
+      traverse_wide8_share<COUNT, false, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
     if(valid)
       storeHit(P, B, par, kind, qi, hit);
   }
   else if(valid)
   {
-    traverse_any<COUNT, WIDE, WT>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc);
+    traverse_any<COUNT, WIDE, TM>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc, raySeed);
     storeHit(P, B, par, kind, qi, hit);
   }
   if(COUNT)
@@ -466,6 +475,9 @@ VKRT_DEV void shadeRound(const TraceParams& P, const WfBuffers& B, const HybridG
   else if((blk -= nP) < nS)
     shadeShadowBlock<HYBRID>(P, B, G, par, cS, blk);
 }
+#if defined(VKRT_EXP) && VKRT_EXP == 4
+__attribute__((amdgpu_waves_per_eu(4)))  // experiment #88: the shade kernel at four waves per SIMD (<= 128 VGPRs) instead of three
+#endif
 __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
 {
   const HybridGi none{};
@@ -563,33 +575,35 @@ void vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B)
   B->capacity = pathCapacity;
 }
 
-// One traversal launch: the instantiation for (instrumented?, node layout, workgroup size, triangle test).  The watertight test is
-// built for the default 64-thread workgroups only (vkrt_accel_build refuses the other sizes with VKRT_OPT_WATERTIGHT).
+// One traversal launch: the instantiation for (instrumented?, node layout, workgroup size, triangle mode).  The non-default triangle
+// modes (watertight test, any-hit dissolve stage) are built for the default 64-thread workgroups only (vkrt_accel_build refuses the
+// other sizes with them).
 static void launchTraverse(const TraceParams& P, const WfBuffers& B, int r, unsigned travBlock, bool count, dim3 tg, size_t tlds, hipStream_t stream)
 {
-  const bool wide = P.sc.layout == 1u, wt = P.sc.watertight != 0u;
+  const bool wide = P.sc.layout == 1u;
+  const int tm = (P.sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (P.sc.dissolve ? VKRT_TM_DISSOLVE : 0);
   const dim3 tb(travBlock);
-#define VKRT_TRAV_LAUNCH(C, W, TB, WT) hipLaunchKernelGGL((k_wf_traverse<C, W, TB, WT>), tg, tb, tlds, stream, P, B, r)
-  if(travBlock == 64 && wt)
+#define VKRT_TRAV_LAUNCH(C, W, TB, TM) hipLaunchKernelGGL((k_wf_traverse<C, W, TB, TM>), tg, tb, tlds, stream, P, B, r)
+#define VKRT_TRAV_MODES(TB, TM)                                                                                                        \
+  do {                                                                                                                                 \
+    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, TB, TM); else VKRT_TRAV_LAUNCH(false, true, TB, TM); }                           \
+    else { if(count) VKRT_TRAV_LAUNCH(true, false, TB, TM); else VKRT_TRAV_LAUNCH(false, false, TB, TM); }                             \
+  } while(0)
+  if(travBlock == 64)
   {
-    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 64, true); else VKRT_TRAV_LAUNCH(false, true, 64, true); }
-    else { if(count) VKRT_TRAV_LAUNCH(true, false, 64, true); else VKRT_TRAV_LAUNCH(false, false, 64, true); }
-  }
-  else if(travBlock == 64)
-  {
-    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 64, false); else VKRT_TRAV_LAUNCH(false, true, 64, false); }
-    else { if(count) VKRT_TRAV_LAUNCH(true, false, 64, false); else VKRT_TRAV_LAUNCH(false, false, 64, false); }
+    switch(tm)
+    {
+      case 0: VKRT_TRAV_MODES(64, 0); break;
+      case 1: VKRT_TRAV_MODES(64, 1); break;
+      case 2: VKRT_TRAV_MODES(64, 2); break;
+      default: VKRT_TRAV_MODES(64, 3); break;
+    }
   }
   else if(travBlock == 128)
-  {
-    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 128, false); else VKRT_TRAV_LAUNCH(false, true, 128, false); }
-    else { if(count) VKRT_TRAV_LAUNCH(true, false, 128, false); else VKRT_TRAV_LAUNCH(false, false, 128, false); }
-  }
+    VKRT_TRAV_MODES(128, 0);
   else
-  {
-    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, 256, false); else VKRT_TRAV_LAUNCH(false, true, 256, false); }
-    else { if(count) VKRT_TRAV_LAUNCH(true, false, 256, false); else VKRT_TRAV_LAUNCH(false, false, 256, false); }
-  }
+    VKRT_TRAV_MODES(256, 0);
+#undef VKRT_TRAV_MODES
 #undef VKRT_TRAV_LAUNCH
 }
 

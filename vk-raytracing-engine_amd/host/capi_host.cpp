@@ -116,6 +116,45 @@ int vkrt_host_render_gltf(const char* path, int device, int width, int height, i
   catch(const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// The hybrid sequence of the reference's frame loop (main.cpp:510-561: rasterizeGltf -> raytraceRasterizedScene -> drawPost)
+// through HelloVkrt for ONE rank of a `world`-rank job (setShard): displayOut receives the rank's display strips (rows of its
+// shard x width x rgba32f, after post.frag).  world = 1: the whole image.  GI on, shadows and AO on.
+int vkrt_host_render_gltf_hybrid(const char* path, int device, int width, int height, int depth, int frames, uint32_t seed0, const float* eye,
+                                 const float* center, const float* up, float fov, uint32_t rank, uint32_t world, float* displayOut)
+{
+  try
+  {
+    HelloVkrt vk(device);
+    vk.setup(width, height);
+    vk.setShard(rank, world);
+    vk.CameraManip.setLookat(Vec3{eye[0], eye[1], eye[2]}, Vec3{center[0], center[1], center[2]}, Vec3{up[0], up[1], up[2]});
+    vk.CameraManip.setFov(fov);
+    vk.loadGltfScene(path);
+    vk.createOffscreenRender();
+    vk.initRayTracing();
+    vk.createBottomLevelASGltf();
+    vk.createTopLevelAsGltf();
+    vk.m_pcRay.samples = 1;
+    vk.m_pcRay.depth = depth;
+    vk.m_pcRay.useShadows = 1; vk.m_pcRay.useAO = 1; vk.m_pcRay.useGI = 1;
+    vk.m_pcPost.rtMode = 0;
+    const float clear[4] = {1, 1, 1, 1};
+    for(int f = 0; f < frames; f++)
+    {
+      vk.updateUniformBuffer();
+      vk.updateFrame();
+      vk.m_seed = seed0 + (uint32_t)f;
+      vk.rasterizeGltf(clear);
+      vk.raytraceRasterizedScene();
+    }
+    std::vector<float> display;
+    vk.drawPost(display);
+    memcpy(displayOut, display.data(), display.size() * sizeof(float));
+    return 0;
+  }
+  catch(const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 int vkrt_host_decode_png(const uint8_t* data, uint64_t size, uint32_t* wh, uint8_t* rgbaOut, uint64_t cap)
 {
   TextureImage t;

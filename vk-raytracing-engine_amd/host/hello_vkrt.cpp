@@ -120,19 +120,25 @@ void HelloVkrt::pathtrace(const float clearColor[4])
     throw std::runtime_error("pathtrace before scene/offscreen image creation");
   for(int k = 0; k < 4; k++) m_pcRay.clearColor[k] = clearColor[k];
   const vkrt_trace_opts opts{m_seed, m_traceFlags};
+  const vkrt_shard shard = launchShard();
+  check(vkrt_pathtrace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, m_offscreenColor, nullptr), "vkrt_pathtrace");
+}
+
+// the launch geometry of this rank: the whole image, or its strips of the full-size launch (setShard)
+vkrt_shard HelloVkrt::launchShard() const
+{
   vkrt_shard shard = m_shard;
   shard.full_width = (uint32_t)m_size.width;
   shard.full_height = (uint32_t)m_size.height;
-  check(vkrt_pathtrace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, m_offscreenColor, nullptr), "vkrt_pathtrace");
+  return shard;
 }
 
 void HelloVkrt::rasterizeGltf(const float clearColor[4])
 {
-  if(m_shard.shard_count > 1)
-    throw std::runtime_error("hybrid mode is single-GPU (setShard applies to the path tracer)");
   if(!m_scene || !m_offscreenColor)
     throw std::runtime_error("rasterizeGltf before scene/offscreen image creation");
-  const vkrt_shard shard{(uint32_t)m_size.width, (uint32_t)m_size.height, 0, 1, 0};
+  // sharded like the path tracer: every plane holds this rank's strips stacked from row 0 (the ABI's shard semantics)
+  const vkrt_shard shard = launchShard();
   const vkrt_gbuffer g{m_offscreenColor, m_positionTexture, m_normalTexture, m_roughnessTexture};
   check(vkrt_gbuffer_raycast(m_scene, clearColor, m_pcRay.lightsCount /* m_pcRaster.lightsCount, :323 */, &m_hostUBO, &shard, &g, nullptr),
         "vkrt_gbuffer_raycast");
@@ -143,17 +149,26 @@ void HelloVkrt::raytraceRasterizedScene()
   if(m_stopAtMaxFrames && m_pcRay.frame >= m_maxFrames)
     return;
   const vkrt_trace_opts opts{m_seed, m_traceFlags};
-  const vkrt_shard shard{(uint32_t)m_size.width, (uint32_t)m_size.height, 0, 1, 0};
+  const vkrt_shard shard = launchShard();
   const vkrt_gbuffer g{m_offscreenColor, m_positionTexture, m_normalTexture, m_roughnessTexture};
   check(vkrt_hybrid_trace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, &g, m_accumulatedTexture, nullptr), "vkrt_hybrid_trace");
 }
 
-void HelloVkrt::drawPost(std::vector<float>& displayRgba)
+const float* HelloVkrt::drawPostDevice()
 {
   m_pcPost.aspectRatio = (float)m_size.width / (float)m_size.height;
   m_pcPost.useGI = m_pcRay.useGI;
-  const uint32_t n = (uint32_t)((size_t)m_size.width * m_size.height);
+  const vkrt_shard shard = launchShard();
+  const uint32_t n = (uint32_t)((size_t)m_size.width * vkrt_shard_rows(&shard));  // per pixel: the strips of this rank, or the whole image
   check(vkrt_post(m_device, &m_pcPost, n, m_offscreenColor, m_accumulatedTexture, m_displayImage, nullptr), "vkrt_post");
+  return m_displayImage;
+}
+
+void HelloVkrt::drawPost(std::vector<float>& displayRgba)
+{
+  const vkrt_shard shard = launchShard();
+  const uint32_t n = (uint32_t)((size_t)m_size.width * vkrt_shard_rows(&shard));
+  drawPostDevice();
   displayRgba.resize((size_t)n * 4);
   if(hipDeviceSynchronize() != hipSuccess ||
      hipMemcpy(displayRgba.data(), m_displayImage, displayRgba.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)

@@ -50,9 +50,11 @@ public:
   void rasterizeGltf(const float clearColor[4]);          // :583-615 (ray-cast G-buffer: no raster path from HIP)
   void raytraceRasterizedScene();                         // :1450-1473
   void drawPost(std::vector<float>& displayRgba);         // :882-897 + post.frag (composite + gamma), downloaded
+  const float* drawPostDevice();                          // the same, left on the device (rows of this rank's shard): what a gather sends
   void onResize(int w, int h);                            // :620-626
   // multi-GPU (one process per GPU): this object renders only the strips of `rank` (vkrt_shard, 16-row strips dealt round-robin);
-  // call before createOffscreenRender.  Path-tracer mode only.  The strips are gathered by StripGather (strip_gather.h).
+  // call before createOffscreenRender.  Both modes: pathtrace() and the hybrid sequence rasterizeGltf / raytraceRasterizedScene /
+  // drawPost work on the rank's strips (every plane holds them stacked from row 0).  Gathered by StripGather (strip_gather.h).
   void setShard(uint32_t rank, uint32_t world);
   const vkrt_shard& shard() const { return m_shard; }
   const float* offscreenDevice() const { return m_offscreenColor; }
@@ -79,6 +81,7 @@ public:
 
 private:
   void check(int rc, const char* what) const;
+  vkrt_shard launchShard() const;
   int m_device;
   vkrt_scene* m_scene = nullptr;
   float* m_offscreenColor = nullptr;  // device rgba32f

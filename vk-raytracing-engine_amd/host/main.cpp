@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <cerrno>
+#include <csignal>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -22,15 +24,32 @@
 using namespace vkrt_host;
 
 // `--ranks N`: one child process per GPU (rank r renders on device r), started before this process touches HIP; the children
-// find each other through the RCCL id file.  Returns the worst child exit code.
+// find each other through the RCCL id file, which lives in a private directory (mkdtemp: mode 0700, unpredictable name, so no
+// other user can plant a file or a symbolic link where rank 0 will write).  The ranks run a collective: if one of them dies --
+// a bad device index, an allocation failure, an exception after ncclCommInitRank -- the others would block for ever in
+// ncclCommInitRank / ncclAllGather.  So the children are reaped in the order they exit, and on the first abnormal or non-zero
+// exit the remaining ones are terminated (SIGTERM, then SIGKILL) and that rank's code is returned.
 static int spawnRanks(int ranks, int argc, char** argv)
 {
   // RCCL between processes needs dmabuf IPC on hosts whose driver has no legacy IPC (hipIpcGetMemHandle: invalid argument otherwise)
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
-  char idFile[64];
-  snprintf(idFile, sizeof idFile, "/tmp/vkrt_rccl_id_%d", (int)getpid());
-  unlink(idFile);
+  char dir[] = "/tmp/vkrt_rccl_XXXXXX";
+  if(!mkdtemp(dir))
+  {
+    perror("mkdtemp");
+    return 1;
+  }
+  const std::string idFile = std::string(dir) + "/id";
   std::vector<pid_t> kids;
+  auto cleanup = [&]() {
+    unlink(idFile.c_str());
+    unlink((idFile + ".tmp").c_str());
+    rmdir(dir);
+  };
+  auto killRest = [&](int sig) {
+    for(pid_t k : kids)
+      if(k > 0) kill(k, sig);
+  };
   for(int r = 0; r < ranks; r++)
   {
     const pid_t pid = fork();
@@ -50,19 +69,57 @@ static int spawnRanks(int ranks, int argc, char** argv)
       perror("execv");
       _exit(127);
     }
-    if(pid < 0) { perror("fork"); return 1; }
+    if(pid < 0)
+    {
+      perror("fork");
+      killRest(SIGTERM);
+      for(pid_t k : kids) waitpid(k, nullptr, 0);
+      cleanup();
+      return 1;
+    }
     kids.push_back(pid);
   }
-  int worst = 0;
-  for(pid_t k : kids)
+  int result = 0;
+  size_t alive = kids.size();
+  bool terminating = false;
+  while(alive > 0)
   {
     int st = 0;
-    waitpid(k, &st, 0);
-    const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
-    worst = rc > worst ? rc : worst;
+    const pid_t done = waitpid(-1, &st, 0);  // whichever rank exits first
+    if(done < 0)
+    {
+      if(errno == EINTR) continue;
+      break;
+    }
+    size_t idx = kids.size();
+    for(size_t k = 0; k < kids.size(); k++)
+      if(kids[k] == done) idx = k;
+    if(idx == kids.size())
+      continue;  // not one of ours
+    kids[idx] = -1;
+    alive--;
+    const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+    if(rc != 0 && !terminating)
+    {
+      fprintf(stderr, "vkrt_render: rank %zu ended with code %d; stopping the other %zu rank(s)\n", idx, rc, alive);
+      result = rc;
+      terminating = true;
+      killRest(SIGTERM);
+      // a rank stuck inside a collective may ignore SIGTERM for a while: give it two seconds, then insist
+      for(int spin = 0; spin < 20 && alive > 0; spin++)
+      {
+        int s2 = 0;
+        pid_t d2;
+        while((d2 = waitpid(-1, &s2, WNOHANG)) > 0)
+          for(size_t k = 0; k < kids.size(); k++)
+            if(kids[k] == d2) { kids[k] = -1; alive--; }
+        if(alive > 0) usleep(100000);
+      }
+      killRest(SIGKILL);
+    }
   }
-  unlink(idFile);
-  return worst;
+  cleanup();
+  return result;
 }
 
 int main(int argc, char** argv)
@@ -109,8 +166,6 @@ int main(int argc, char** argv)
     std::unique_ptr<StripGather> gather;
     if(gatherMode)
     {
-      if(cfg.mode == "hybrid")
-        throw std::runtime_error("multi-GPU strips apply to the path tracer (mode \"pathtrace\")");
       StripLayout L;
       L.width = (uint32_t)cfg.width; L.height = (uint32_t)cfg.height; L.stripRows = 16; L.world = (uint32_t)world;
       gather.reset(new StripGather(L, (uint32_t)rank, device, idFile));
@@ -154,6 +209,8 @@ int main(int argc, char** argv)
       {
         helloVk.rasterizeGltf(cfg.clearColor);                  // main.cpp:513
         helloVk.raytraceRasterizedScene();                      // main.cpp:547
+        if(gather && f + 1 == cfg.frames)  // the ranks composite their own strips (post.frag is per pixel); the display strips travel
+          gather->gather(helloVk.drawPostDevice(), nullptr);
       }
       traceMs += helloVk.lastTraceMs();
     }
@@ -171,6 +228,11 @@ int main(int argc, char** argv)
       {
         std::vector<float> img((size_t)cfg.width * cfg.height * 4);
         if(hipMemcpy(img.data(), gather->fullImage(), img.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("hipMemcpy failed");
+        if(hybrid)
+        {  // what was gathered is the display image (after post.frag's gamma): PNG as is, linear values for the PFM / PPM writers
+          writePNG(out + ".png", img, cfg.width, cfg.height);
+          for(float& v : img) v = std::pow(v, 2.2f);
+        }
         writePFM(out + ".pfm", img, cfg.width, cfg.height);
         writePPM(out + ".ppm", img, cfg.width, cfg.height);
         printf("rank 0 of %d wrote %s.pfm / %s.ppm (strips gathered with one RCCL all-gather)\n", world, out.c_str(), out.c_str());

@@ -1,6 +1,9 @@
 // strip_gather.cpp -- RCCL side of the multi-GPU gather (strip_gather.h): libvkrt_gather.so, linked by vkrt_render.
 #include "strip_gather.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <rccl/rccl.h>
 #include <unistd.h>
 
@@ -35,12 +38,17 @@ StripGather::StripGather(const StripLayout& L, uint32_t rank, int device, const 
   if(rank == 0)
   {
     ncclOk(ncclGetUniqueId(&id), "ncclGetUniqueId");
+    // written under a temporary name and renamed, so a reader never sees a partial id; the temporary file is created exclusively
+    // and without following a symbolic link (a pre-planted name makes the open fail instead of redirecting the write)
     const std::string tmp = idFile + ".tmp";
-    std::ofstream f(tmp, std::ios::binary);
-    f.write((const char*)&id, sizeof id);
-    f.close();
-    if(!f || rename(tmp.c_str(), idFile.c_str()) != 0)
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+    bool ok = fd >= 0 && write(fd, &id, sizeof id) == (ssize_t)sizeof id;
+    if(fd >= 0) ok = (close(fd) == 0) && ok;
+    if(!ok || rename(tmp.c_str(), idFile.c_str()) != 0)
+    {
+      if(fd >= 0) unlink(tmp.c_str());
       throw std::runtime_error("StripGather: cannot publish the RCCL id in " + idFile);
+    }
   }
   else
   {

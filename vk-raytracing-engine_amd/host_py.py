@@ -32,6 +32,9 @@ def lib():
         L.vkrt_host_render_gltf.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p]
         L.vkrt_host_render_gltf.restype = C.c_int
+        L.vkrt_host_render_gltf_hybrid.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_float, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.vkrt_host_render_gltf_hybrid.restype = C.c_int
         L.vkrt_host_decode_png.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
         L.vkrt_host_decode_png.restype = C.c_int
         L.vkrt_host_decode_image.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -124,6 +127,18 @@ def render_gltf(path, width, height, samples=1, depth=3, frames=1, seed0=0, eye=
                                      c.ctypes.data, p.ctypes.data, fov, build, img.ctypes.data)
     if rc != 0:
         raise RuntimeError("vkrt_host_render_gltf: " + lib().vkrt_host_last_error().decode())
+    return img
+
+
+def render_gltf_hybrid(path, width, height, depth=3, frames=1, seed0=0, eye=(0, 0, 15), center=(0, 0, 0), up=(0, 1, 0), fov=60.0, rank=0, world=1, device=0):
+    """The reference's hybrid frame sequence through the C++ HelloVkrt for one rank of `world`: that rank's display strips [rows, W, 4]."""
+    rows = strip_rows(height, world, rank) if world > 1 else height
+    img = np.zeros((rows, width, 4), np.float32)
+    e, c, p = (np.asarray(v, np.float32) for v in (eye, center, up))
+    rc = lib().vkrt_host_render_gltf_hybrid(os.fsencode(path), device, width, height, depth, frames, seed0, e.ctypes.data, c.ctypes.data, p.ctypes.data, fov,
+                                            rank, world, img.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("vkrt_host_render_gltf_hybrid: " + lib().vkrt_host_last_error().decode())
     return img
 
 
