@@ -2,11 +2,11 @@
 # One gpurun call producing the artefacts kept under profiles/: GPU tests, default bench line, rocprofv3
 # kernel-trace stats of the same command, and separate --pmc passes for FETCH_SIZE / WRITE_SIZE.
 set -o pipefail
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; TAG=${1:-r03}
 rm -rf $OUT; mkdir -p $OUT
 step() { local name=$1 secs=$2; shift 2; timeout -k 10 $secs "$@" > $OUT/$name.log 2>&1; local rc=$?; echo "$name rc=$rc" | tee -a $OUT/round.log; [ $rc -ge 124 ] && { echo TIMEOUT | tee -a $OUT/round.log; exit $rc; }; return 0; }
 : > $OUT/round.log
-step pytest 600 python -m pytest tests -m gpu -q
+step pytest 900 python -m pytest tests -m gpu -q
 export TMPDIR=/tmp
 cd /tmp
 # per-kernel durations that bench.py's roofline must agree with are those of un-overlapped launches: one sub-frame

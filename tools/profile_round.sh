@@ -21,12 +21,15 @@ pass() { # index, counters...
   local i=$1; shift
   echo "=== pmc set $i: $*" >> $OUT/profile_round.log
   rm -rf $OUT/pmc/set$i
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc/set$i -- $B > $OUT/pmc/set$i.log 2>&1 &
+  # the pass runs in a session (= process group) of its own: a background job of a non-interactive script otherwise shares the
+  # script's group, and killing "the pass's group" would take this script -- and whatever launched it -- down with it
+  setsid timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc/set$i -- $B > $OUT/pmc/set$i.log 2>&1 &
   local pid=$!
   while kill -0 $pid 2>/dev/null; do
     if grep -qE "error code 38|Could not construct profile cfg" $OUT/pmc/set$i.log 2>/dev/null; then
       echo "pmc set $i: counter set does not fit the hardware (error 38): killing the pass and stopping" | tee -a $OUT/profile_round.log
-      kill -- -$(ps -o pgid= $pid | tr -d ' ') 2>/dev/null || kill $pid 2>/dev/null
+      local pg=$(ps -o pgid= $pid | tr -d ' ')
+      if [ -n "$pg" ] && [ "$pg" != "$(ps -o pgid= $$ | tr -d ' ')" ]; then kill -TERM -- -$pg 2>/dev/null; sleep 2; kill -KILL -- -$pg 2>/dev/null; else kill $pid 2>/dev/null; fi
       wait $pid 2>/dev/null
       exit 38
     fi
