@@ -439,7 +439,8 @@ def main():
             orc = oracle_py.OracleScene(flat, build_bvh=True, max_leaf=4)
             frame = args.warmup  # the first timed frame
             pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
-            threads = min(16, os.cpu_count() or 1)  # the 1-GPU box grants 16 CPUs
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = min(16, avail)  # the 1-GPU box grants 16 CPUs of its host
 
             def sample(nthreads, seconds):
                 """rows of the frame rendered by the oracle for about `seconds` of wall time on `nthreads` threads"""
@@ -470,7 +471,7 @@ def main():
                           f"full-sweep SAH BVH2 <=4 tris/leaf",
                 "single_thread": {"value": cpu_rays1 / cpu_s1 / 1e6, "unit": "Mrays/s", "cores": 1,
                                   "sample": f"{len(rows1)} rows ({cpu_rays1} rays, {cpu_s1:.1f} s)"},
-                "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+                "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "cpus_available_to_this_process": avail,
             }
             if "roofline" in out and out["roofline"].get("kernel") == "k_wf_traverse":
                 tb = (64 * c["nodes_visited"] + 48 * c["tris_tested"]) / cpu_rays

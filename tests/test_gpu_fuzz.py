@@ -1,6 +1,7 @@
 """A slice of the randomised differential campaign (tools/fuzz_parity.py): random scenes, cameras, builders and options, the HIP
 path tracer and the hybrid passes against the CPU oracle, bit for bit.  The long runs are in profiles/r02_fuzz_parity.json
-(137 k cases; findings and fixes listed there); this keeps 120 fixed seeds in the driver's GPU pass."""
+(137 k cases) and profiles/r03_fuzz_parity.json (the round-3 options: watertight test, any-hit dissolve stage, dead-shadow-ray
+skipping; findings and fixes listed there); this keeps 120 fixed seeds and the recorded finding seeds in the driver's GPU pass."""
 import os
 import sys
 
@@ -38,6 +39,23 @@ def test_needle_case_of_the_round2_campaign(watertight):
 
     info, problems = fuzz_parity.run_case(1301004260, force_opts={abi.VKRT_OPT_WATERTIGHT: watertight})
     assert info["opts"].get(abi.VKRT_OPT_BVH_LAYOUT) == 0 and info["kind"] == "ploc"
+    assert not problems, problems
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [31004365, 31006136])
+def test_watertight_sliver_cases_of_the_round3_campaign(seed):
+    """Found by the round-3 campaign under VKRT_OPT_WATERTIGHT: a 1320-unit sliver in the plane y = 0 and bounce rays that start on
+    it.  Woop's distance -- the barycentric average of the sheared vertex depths -- carried the vertices' depth range times the
+    rounding of (U, V, W): t = 0.008 for a ray leaving the very surface, past tmin = 0.001, a self-hit the loop over all triangles
+    accepts and the box tests rightly prune (tree-dependent).  The watertight test now takes its distance from the triangle's plane
+    (exact to ~eps |p0 - o| / cos, 0 for an origin in the plane); the (U, V, W) decision, which is what makes it watertight, is
+    unchanged.  Both cases replay with their own draw of options (watertight, clustered / radix build, work sharing 40)."""
+    import fuzz_parity
+    from vkrt_amd import abi
+
+    info, problems = fuzz_parity.run_case(seed)
+    assert info["opts"].get(abi.VKRT_OPT_WATERTIGHT) == 1
     assert not problems, problems
 
 

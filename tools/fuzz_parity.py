@@ -225,6 +225,9 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
                 info["needle_limit_pixels"] = int((~same.all(-1)).sum())
             else:
                 problems.append(("pathtrace", frac, float(np.nanmax(np.abs(got - ref)))))
+        if hook is not None and not same.all():  # tools/debug_case.py: localise a path-tracer mismatch
+            hook(dict(stage="pathtrace", flat=flat, renderer=r, oracle=orc, cam=cam, W=W, H=H, got=got, ref=ref, seed=seed, flags=flags, kind=kind, opts=opts,
+                      spp=spp, depth=depth, L=L, first_frame=first_frame, frames=frames))
         c = r.counters()
         info["rays"] = int(c["rays_closest"] + c["rays_shadow"])
         info["lit"] = float((np.nan_to_num(got[..., :3]).sum(-1) > 0).mean())
@@ -324,7 +327,7 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
             else:
                 info["oracle_tree_differs_from_brute_force"] = True
         if hook is not None:  # tools/debug_case.py: everything a replay needs to look at single pixels / rays
-            hook(dict(flat=flat, renderer=r, oracle=orc, cam=cam, pc=pc, W=W, H=H, gbuffer=gnp, acc=acc, accr=accr, seed=seed, flags=flags, kind=kind, opts=opts))
+            hook(dict(stage="hybrid", flat=flat, renderer=r, oracle=orc, cam=cam, pc=pc, W=W, H=H, gbuffer=gnp, acc=acc, accr=accr, seed=seed, flags=flags, kind=kind, opts=opts))
     finally:
         r.close()
     if verbose or problems:
@@ -338,19 +341,21 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None, help="replay one case")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"))
+    ap.add_argument("--force-opt", action="append", default=[], metavar="ID=VALUE", help="apply this execution option to every case (e.g. 10=1: the watertight test)")
     a = ap.parse_args()
+    force = {int(k): int(v) for k, v in (x.split("=") for x in a.force_opt)} or None
     if a.only is not None:
-        run_case(a.only, verbose=True)
+        run_case(a.only, verbose=True, force_opts=force)
         return 0
     t0 = time.time()
     n = bad = 0
     failures = []
-    tris = rays = tree_notes = needle_notes = 0
+    tris = rays = tree_notes = needle_notes = needle_notes_wt = n_wt = n_dissolve = n_skip = 0
     lit = 0.0
     while time.time() - t0 < a.seconds:
         seed = a.seed * 1000003 + n
         try:
-            info, problems = run_case(seed)
+            info, problems = run_case(seed, force_opts=force)
         except Exception as e:  # an API error is a finding too
             info, problems = dict(seed=seed), [("exception", repr(e), 0)]
             print(json.dumps({"seed": seed, "exception": repr(e)}), flush=True)
@@ -358,6 +363,11 @@ def main():
         tris += info.get("tris", 0)
         tree_notes += 1 if info.get("oracle_tree_differs_from_brute_force") else 0
         needle_notes += 1 if info.get("needle_limit_pixels") else 0
+        o = info.get("opts", {})
+        n_wt += 1 if o.get(abi.VKRT_OPT_WATERTIGHT) else 0
+        n_dissolve += 1 if o.get(abi.VKRT_OPT_ANYHIT_DISSOLVE) else 0
+        n_skip += 1 if o.get(abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS) else 0
+        needle_notes_wt += 1 if (info.get("needle_limit_pixels") and o.get(abi.VKRT_OPT_WATERTIGHT)) else 0
         rays += info.get("rays", 0)
         lit += info.get("lit", 0.0)
         if problems:
@@ -365,9 +375,10 @@ def main():
             failures.append({**info, "problems": problems})
         if n % 50 == 0:
             print(f"[{time.time() - t0:6.0f} s] {n} cases, {bad} with findings", flush=True)
-    out = {"cases": n, "with_findings": bad, "seconds": round(time.time() - t0, 1), "triangles_total": tris, "rays_total": rays, "mean_lit_pixel_fraction": round(lit / max(n, 1), 3),
+    out = {"forced_options": force, "cases": n, "with_findings": bad, "seconds": round(time.time() - t0, 1), "triangles_total": tris, "rays_total": rays, "mean_lit_pixel_fraction": round(lit / max(n, 1), 3),
            "cases_where_only_the_oracle_tree_walk_differed_from_brute_force": tree_notes,
-           "cases_at_the_needle_limit": needle_notes, "first_seed": a.seed * 1000003, "failures": failures[:50]}
+           "cases_at_the_needle_limit": needle_notes, "cases_at_the_needle_limit_with_the_watertight_test": needle_notes_wt,
+           "cases_with_the_watertight_test": n_wt, "cases_with_the_anyhit_dissolve_stage": n_dissolve, "cases_skipping_dead_shadow_rays": n_skip, "first_seed": a.seed * 1000003, "failures": failures[:50]}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1, default=str)
     print(json.dumps({k: v for k, v in out.items() if k != "failures"}))

@@ -16,7 +16,7 @@ W, H = int(os.environ.get("PROBE_W", 3840)), int(os.environ.get("PROBE_H", 2160)
 SPP, DEPTH = int(os.environ.get("PROBE_SPP", 16)), 8
 flat, info = atrium.build_atrium(262144, seed=1)
 cam = host_py.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA)
-r = Renderer(flat, device=0, build="sah")
+r = Renderer(flat, device=0, build=os.environ.get("BUILD", "ploc"))
 
 
 def frames(shard, n=2):
