@@ -45,6 +45,27 @@ def test_argument_validation_and_no_cpu_fallback(cornell_flat):
     desc, keep = cornell_flat.to_desc()
     desc.light_count = 0
     assert lib.vkrt_scene_create(C.byref(desc), 0, C.byref(h)) == 1
+    # non-finite geometry has no place in an acceleration structure: refused up front (round 3), positions and node matrices alike
+    import copy
+
+    import numpy as np
+
+    for field, index in (("positions", (5, 1)), ("nodes", 0)):
+        bad = copy.deepcopy(cornell_flat)
+        if field == "positions":
+            bad.positions[index] = np.nan
+        else:
+            m = np.array(bad.nodes[index]["worldMatrix"], np.float32); m[3] = np.inf
+            bad.nodes[index]["worldMatrix"] = m
+        desc, keep = bad.to_desc()
+        assert lib.vkrt_scene_create(C.byref(desc), 0, C.byref(h)) == 1
+        assert b"not finite" in lib.vkrt_last_error() and not h.value
+    # options 10-12 exist (watertight test, dead-shadow-ray skipping, any-hit dissolve stage); 13 does not
+    from vkrt_amd import abi
+
+    assert (abi.VKRT_OPT_WATERTIGHT, abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, abi.VKRT_OPT_ANYHIT_DISSOLVE) == (10, 11, 12)
+    hdr = open(os.path.join(ROOT, "include", "vkrt.h")).read()
+    assert "VKRT_OPT_LAST            = 12" in hdr
     desc, keep = cornell_flat.to_desc()
     if lib.vkrt_device_count() == 0:
         # the product never computes on the CPU: without a device creation must fail loudly
