@@ -344,10 +344,9 @@ inline WtRay wt_prepare(V3 d)
   return R;
 }
 inline V3 wt_permute(int kz, V3 v) { return kz == 0 ? v3(v.y, v.z, v.x) : (kz == 1 ? v3(v.z, v.x, v.y) : v); }
-inline bool isect_tri_wt(const WtRay& R, V3 o, V3 d, const Tri& tr, float& t, float& u, float& v)
+inline bool isect_tri_wt(const WtRay& R, V3 o, const Tri& tr, float& t, float& u, float& v)
 {
-  const V3 A0 = tr.v0 - o;
-  const V3 A = wt_permute(R.kz, A0), B = wt_permute(R.kz, tr.p1 - o), C = wt_permute(R.kz, tr.p2 - o);
+  const V3 A = wt_permute(R.kz, tr.v0 - o), B = wt_permute(R.kz, tr.p1 - o), C = wt_permute(R.kz, tr.p2 - o);
   const float Ax = A.x - R.Sx * A.z, Ay = A.y - R.Sy * A.z;
   const float Bx = B.x - R.Sx * B.z, By = B.y - R.Sy * B.z;
   const float Cx = C.x - R.Sx * C.z, Cy = C.y - R.Sy * C.z;
@@ -363,15 +362,15 @@ inline bool isect_tri_wt(const WtRay& R, V3 o, V3 d, const Tri& tr, float& t, fl
   const float det = (U + V) + W;
   if(det == 0.0f)
     return false;
-  // distance from the plane through p0 (not the paper's barycentric average of the sheared depths, whose error grows with the
-  // triangle's depth range: seed 31004365 of the round-3 campaign; see csrc/traverse.h tri_test_wt)
-  const V3 e1 = tr.p1 - tr.v0, e2 = tr.p2 - tr.v0;
-  const V3 N = cross(e1, e2);
-  const float den = dot(N, d);
+  // distance from the triangle's plane (not the paper's barycentric average of the sheared depths, whose error grows with the
+  // triangle's depth range: seed 31004365 of the round-3 campaign), on the translated, permuted vertices: N.d' = d'z (Nx Sx + Ny Sy
+  // + Nz), 1 / d'z = Sz; see csrc/traverse.h tri_test_wt
+  const V3 N = cross(B - A, C - A);
+  const float den = (N.x * R.Sx + N.y * R.Sy) + N.z;
   if(den == 0.0f)
     return false;
   const float inv = 1.0f / det;
-  t = dot(N, A0) / den;
+  t = (dot(N, A) * R.Sz) / den;
   u = V * inv;
   v = W * inv;
   return true;
@@ -404,7 +403,7 @@ struct TriTester
   }
   bool operator()(V3 o, V3 d, const Tri& tr, float& t, float& u, float& v) const
   {
-    return wt ? isect_tri_wt(R, o, d, tr, t, u, v) : isect_tri(o, d, tr, t, u, v);
+    return wt ? isect_tri_wt(R, o, tr, t, u, v) : isect_tri(o, d, tr, t, u, v);
   }
   // true: the candidate hit on `tr` is ignored (ignoreIntersectionEXT)
   bool ignores(const Tri& tr) const

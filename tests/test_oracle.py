@@ -382,5 +382,17 @@ def test_dissolve_stage_passes_the_expected_fraction_of_rays():
         t, _, _, gid, _ = orc.trace_rays(o, d)
         through = float(np.mean(gid >= len(idx) // 3))  # hit the backdrop (its two triangles come last)
         assert abs(through - (1.0 - alpha)) < 0.03, (alpha, through)
+        # ray by ray against an independent statement of the rule (numpy tea / lcg of oracle/np_pathtrace.py): the screen triangle
+        # under the ray (opaque query) is ignored iff alpha == 0 or rnd(tea(triangle id, payload seed = 0)) > alpha
+        import np_pathtrace
+
+        orc.set_dissolve(False)
+        _, _, _, under, _ = orc.trace_rays(o, d)
+        orc.set_dissolve(True)
+        assert np.all(under < len(idx) // 3)
+        st = np_pathtrace.tea(under.astype(np.uint32), np.zeros_like(under, dtype=np.uint32))
+        _, r = np_pathtrace.rnd(st)
+        expect_ignored = (r > np.float32(alpha)) | (alpha == 0.0)
+        assert np.array_equal(gid >= len(idx) // 3, expect_ignored)
         _, _, _, anyh, _ = orc.trace_rays(o, d, tmin=0.001, tmax=2.5, any_hit=True)  # shadow-type query that ends before the backdrop
         assert abs(float(np.mean(anyh < 0)) - (1.0 - alpha)) < 0.03

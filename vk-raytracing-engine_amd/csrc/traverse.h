@@ -105,10 +105,9 @@ VKRT_DEV WtRay wt_prepare(f3 d)
 }
 // (x, y, z) of v in the permuted frame
 VKRT_DEV f3 wt_permute(int kz, f3 v) { return kz == 0 ? mk3(v.y, v.z, v.x) : (kz == 1 ? mk3(v.z, v.x, v.y) : v); }
-VKRT_DEV bool tri_test_wt(const WtRay& R, f3 o, f3 d, f3 p0, f3 p1, f3 p2, float& t, float& u, float& v)
+VKRT_DEV bool tri_test_wt(const WtRay& R, f3 o, f3 p0, f3 p1, f3 p2, float& t, float& u, float& v)
 {
-  const f3 A0 = p0 - o;
-  const f3 A = wt_permute(R.kz, A0), B = wt_permute(R.kz, p1 - o), C = wt_permute(R.kz, p2 - o);
+  const f3 A = wt_permute(R.kz, p0 - o), B = wt_permute(R.kz, p1 - o), C = wt_permute(R.kz, p2 - o);
   const float Ax = A.x - R.Sx * A.z, Ay = A.y - R.Sy * A.z;
   const float Bx = B.x - R.Sx * B.z, By = B.y - R.Sy * B.z;
   const float Cx = C.x - R.Sx * C.z, Cy = C.y - R.Sy * C.z;
@@ -124,18 +123,19 @@ VKRT_DEV bool tri_test_wt(const WtRay& R, f3 o, f3 d, f3 p0, f3 p1, f3 p2, float
   const float det = (U + V) + W;
   if(det == 0.0f)
     return false;
-  // Distance: from the plane through p0 (unnormalised geometric normal), not the paper's barycentric average of the sheared vertex
+  // Distance: from the triangle's plane (unnormalised geometric normal), not the paper's barycentric average of the sheared vertex
   // depths.  With vertices hundreds of units apart that average carries their depth range times the rounding of (U, V, W) -- 0.008
   // in t on a 1320-unit sliver of the round-3 campaign (seed 31004365), enough to pass tmin = 0.001 and re-hit the very surface a
   // bounce ray starts from, a "hit" the box tests rightly prune: tree-dependent.  The plane form is exact to ~eps |p0 - o| / cos
-  // and gives 0 for an origin in the plane.  Watertightness is a property of the (U, V, W) decision above and is not touched.
-  const f3 e1 = p1 - p0, e2 = p2 - p0;
-  const f3 N = cross3(e1, e2);
-  const float den = dot3(N, d);
+  // and gives 0 for an origin in the plane.  Evaluated on the translated, permuted vertices already at hand: with d' the permuted
+  // direction, N.d' = d'z (Nx Sx + Ny Sy + Nz) and 1 / d'z = Sz.  Watertightness is a property of the (U, V, W) decision above
+  // and is not touched.
+  const f3 N = cross3(B - A, C - A);
+  const float den = (N.x * R.Sx + N.y * R.Sy) + N.z;
   if(den == 0.0f)
     return false;
   const float inv = 1.0f / det;
-  t = dot3(N, A0) / den;
+  t = (dot3(N, A) * R.Sz) / den;
   u = V * inv;   // barycentric weights: U -> p0, V -> p1, W -> p2; (u, v) weigh p1 and p2 like Moeller-Trumbore's
   v = W * inv;
   return true;   // (a NaN anywhere leaves t NaN: every caller's `t > tmin` rejects it)
@@ -160,9 +160,9 @@ template <> struct TriRay<true>
 {
   WtRay R;
   VKRT_DEV void set(f3 d) { R = wt_prepare(d); }
-  VKRT_DEV bool hit(f3 o, f3 d, float4 a, float4 b, float4 c, float& t, float& u, float& v) const
+  VKRT_DEV bool hit(f3 o, f3, float4 a, float4 b, float4 c, float& t, float& u, float& v) const
   {
-    return tri_test_wt(R, o, d, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v);
+    return tri_test_wt(R, o, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v);
   }
 };
 
