@@ -386,6 +386,25 @@ def test_bench_multi_rank_rehearsal(tmp_path):
     assert len(d["config"]["per_rank_ms_per_step"]) == 2 and d["config"]["imbalance_max_over_mean"] >= 1.0
 
 
+def test_bench_starts_its_own_ranks_on_the_gpu():
+    """`python bench.py --gpus 2` with NO launcher and no WORLD_SIZE -- how a driver may call the N > 1 case -- starts the two ranks
+    itself (torch.distributed.run as a child of a parent that never touches the GPU) and relays rank 0's line; strong scaling is the
+    default at N > 1 (one frame split into strips).  Two ranks share the one GPU over gloo here."""
+    import json, os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--rehearse-on-one-gpu",
+           "--triangles", "20000", "--width", "640", "--height", "360", "--spp", "2", "--depth", "3"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and (d["config"]["width"], d["config"]["height"]) == (640, 360)
+    assert "launching" in p.stderr and "torch.distributed.run" in p.stderr
+
+
 def _coincident_layers_scene(layers=5, n=12):
     """A floor of n x n quads instanced `layers` times at the SAME place with different materials, plus a tilted copy that
     crosses it: every primary ray meets `layers` triangles at exactly the same t, so the closest-hit tie rule (smallest
