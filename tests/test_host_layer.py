@@ -612,3 +612,48 @@ def test_vkrt_render_hybrid_through_the_rank_launcher(tmp_path, small_atrium):
     a, _ = imgdiff.read_image(str(tmp_path / "a.pfm"))
     b, _ = imgdiff.read_image(str(tmp_path / "b.pfm"))
     assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_cli_library_options_from_config_json(tmp_path, small_atrium):
+    """config.json keys "watertight" / "anyHitDissolve" / "skipDeadShadowRays" reach the library through HelloVkrt (applied before the
+    acceleration-structure build): the CLI's image equals the oracle's under the same switches, and the dissolve stage visibly changes
+    a scene that has translucent materials."""
+    import copy
+    import subprocess
+
+    import atrium
+    import gltf_export
+    import gltf_flatten
+    import imgdiff
+    import oracle_py
+    from vkrt_amd.flat_scene import make_push_constants
+
+    flat = copy.deepcopy(small_atrium)
+    flat.materials["pbrBaseColorFactor"][0:24:3, 3] = 0.35  # every third material translucent
+    flat.materials["pbrBaseColorFactor"][1, 3] = 0.0        # one invisible
+    path = str(tmp_path / "scene.gltf")
+    gltf_export.export_gltf(flat, path)
+    W, H = 128, 72
+    cam = atrium.DEFAULT_CAMERA
+    base = {"scenes": ["scene.gltf"], "scene": 0, "vsync": False, "width": W, "height": H, "samples": 2, "depth": 4, "frames": 2, "seed": 9,
+            "camera": {"eye": list(cam["eye"]), "center": list(cam["center"]), "up": list(cam["up"]), "fov": cam["fov"]}}
+    exe = os.path.join(ROOT, "vk-raytracing-engine_amd", "vkrt_render")
+    images = {}
+    for name, extra in (("plain", {}), ("options", {"watertight": True, "anyHitDissolve": True, "skipDeadShadowRays": True})):
+        (tmp_path / f"{name}.json").write_text(json.dumps({**base, **extra, "output": str(tmp_path / name)}))
+        p = subprocess.run([exe, "--config", str(tmp_path / f"{name}.json")], capture_output=True, text=True, timeout=180)
+        assert p.returncode == 0, p.stderr
+        images[name], _ = imgdiff.read_image(str(tmp_path / f"{name}.pfm"))
+    assert np.mean(np.abs(images["plain"] - images["options"]).max(-1) > 1e-3) > 0.02  # translucent materials let light and rays through
+    f2 = gltf_flatten.load_gltf(path)
+    assert abs(float(f2.materials["pbrBaseColorFactor"][0, 3]) - 0.35) < 1e-6  # alpha survives the export / ingest
+    orc = oracle_py.OracleScene(f2)
+    orc.set_watertight(True); orc.set_dissolve(True)
+    u = host_py.global_uniforms(width=W, height=H, **cam)
+    ref = np.zeros((H, W, 4), np.float32)
+    for f in range(2):
+        pc = make_push_constants(samples=2, depth=4, frame=f, lights_count=len(f2.lights))
+        orc.render(pc, u, W, H, seed=9 + f, image=ref)
+    got = images["options"]
+    assert np.mean(np.any(got[..., :3].view(np.uint32) != ref[..., :3].view(np.uint32), axis=-1)) < 1e-4

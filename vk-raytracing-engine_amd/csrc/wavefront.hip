@@ -478,6 +478,9 @@ VKRT_DEV void shadeRound(const TraceParams& P, const WfBuffers& B, const HybridG
 #if defined(VKRT_EXP) && VKRT_EXP == 4
 __attribute__((amdgpu_waves_per_eu(4)))  // experiment #88: the shade kernel at four waves per SIMD (<= 128 VGPRs) instead of three
 #endif
+#if defined(VKRT_EXP) && VKRT_EXP == 5
+__attribute__((amdgpu_waves_per_eu(5)))  // experiment #93: the traversal kernel's register footprint (96 VGPRs, spills to scratch): interchangeable wave slots
+#endif
 __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
 {
   const HybridGi none{};

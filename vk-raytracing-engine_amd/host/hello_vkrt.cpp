@@ -65,6 +65,10 @@ void HelloVkrt::createTopLevelAsGltf()
 {
   if(!m_scene || !m_blasRequested)
     throw std::runtime_error("createTopLevelAsGltf before createBottomLevelASGltf");
+  // per-handle options the acceleration-structure build consumes (include/vkrt.h): the triangle test, the any-hit stage
+  check(vkrt_scene_set_option(m_scene, VKRT_OPT_WATERTIGHT, m_watertight ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_WATERTIGHT)");
+  check(vkrt_scene_set_option(m_scene, VKRT_OPT_ANYHIT_DISSOLVE, m_anyHitDissolve ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_ANYHIT_DISSOLVE)");
+  check(vkrt_scene_set_option(m_scene, VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, m_skipDeadShadowRays ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_SKIP_DEAD_SHADOW_RAYS)");
   check(vkrt_accel_build(m_scene, m_buildFlags, nullptr), "vkrt_accel_build");
 }
 
@@ -250,6 +254,9 @@ AppConfig parseConfig(const std::string& text)
   c.useShadows = j["useShadows"].boolean(c.useShadows);
   c.useAO = j["useAO"].boolean(c.useAO);
   c.useGI = j["useGI"].boolean(c.useGI);
+  c.watertight = j["watertight"].boolean(c.watertight);
+  c.anyHitDissolve = j["anyHitDissolve"].boolean(c.anyHitDissolve);
+  c.skipDeadShadowRays = j["skipDeadShadowRays"].boolean(c.skipDeadShadowRays);
   c.output = j["output"].string("");
   if(j.has("clearColor"))
     for(int k = 0; k < 4; k++) c.clearColor[k] = (float)j["clearColor"][(size_t)k].number(1.0);

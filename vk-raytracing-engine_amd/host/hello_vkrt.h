@@ -76,6 +76,10 @@ public:
   struct { int width = 1280, height = 720; } m_size;
   uint32_t m_seed = 0;            // replaces int(clockARB()) (raytrace.rgen:27); advanced every frame
   uint32_t m_buildFlags = VKRT_BUILD_DEFAULT;
+  // library options without a counterpart in the reference class (include/vkrt.h vkrt_option); applied by createTopLevelAsGltf
+  bool m_watertight = false;          // VKRT_OPT_WATERTIGHT: the watertight triangle test a Vulkan driver runs, instead of Moeller-Trumbore
+  bool m_anyHitDissolve = false;      // VKRT_OPT_ANYHIT_DISSOLVE: the any-hit stage hello_vulkan.cpp:1185-1191 keeps commented out
+  bool m_skipDeadShadowRays = false;  // VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: same pixels, fewer shadow rays
   uint32_t m_traceFlags = 0;
   PushConstantPost m_pcPost{1.0f, 0, 0, 0};  // rtMode 0 = hybrid (hello_vulkan.cpp:917), 1 = path tracer
 
@@ -117,6 +121,7 @@ struct AppConfig
   std::string build = "ploc";  // "ploc" (device, default) | "lbvh" (device, fastest build) | "sah" (host)
   std::string mode = "pathtrace";
   bool useShadows = true, useAO = true, useGI = false;  // hello_vulkan.cpp:913-915
+  bool watertight = false, anyHitDissolve = false, skipDeadShadowRays = false;  // library options (include/vkrt.h), all off by default
   std::string output;
   std::string scenePath() const { return scenes.at((size_t)scene); }
 };

@@ -181,6 +181,7 @@ int main(int argc, char** argv)
     helloVk.createOffscreenRender();                            // main.cpp:228
     helloVk.initRayTracing();                                   // main.cpp:235
     helloVk.m_buildFlags = cfg.build == "lbvh" ? VKRT_BUILD_LBVH_GPU : cfg.build == "sah" ? VKRT_BUILD_SAH_HOST : VKRT_BUILD_PLOC_GPU;
+    helloVk.m_watertight = cfg.watertight; helloVk.m_anyHitDissolve = cfg.anyHitDissolve; helloVk.m_skipDeadShadowRays = cfg.skipDeadShadowRays;
     helloVk.createBottomLevelASGltf();                          // main.cpp:236
     helloVk.createTopLevelAsGltf();                             // main.cpp:237
     helloVk.m_pcRay.samples = cfg.samples;
