@@ -197,7 +197,13 @@ enum vkrt_option {
   VKRT_OPT_WF_SHARE        = 5, /* idle lanes of a traversal wave needed before they adopt subtrees, 0 = off (default 16) [build]; env VKRT_WF_SHARE */
   VKRT_OPT_TRI_THRESHOLD   = 6, /* lanes with pending triangles before a wave tests them, 0 = test at once (default 1) [build]; env VKRT_TRI_THRESHOLD */
   VKRT_OPT_WF_SHARE_PERIOD = 7, /* sharing attempted on steps with (step & mask) == mask (default 0 = every step) [build]; env VKRT_WF_SHARE_PERIOD */
-  VKRT_OPT_WF_SHARE_FLAGS  = 8, /* bit 0: lanes with an empty stack also donate a pending child of their current group [build]; env VKRT_WF_SHARE_FLAGS */
+  VKRT_OPT_WF_SHARE_FLAGS  = 8, /* bit 0: lanes with an empty stack also donate a pending child of their current group.  Bits 1-3: child order of
+                                   any-hit (shadow / AO) walks -- "is anything in the way" has the same answer in any order, so this is a cost
+                                   heuristic only: bit 1 = always the FARTHEST pending child first; bit 2 = farthest first for rays that end outside
+                                   the bounds of the scene (a shadow ray towards a light outside the building is stopped by the building's shell,
+                                   the last thing a front-to-back walk reaches), front to back otherwise; bit 3 = automatic: like bit 2 unless the
+                                   scene has room-sized triangles, which a front-to-back walk meets at once.  Default 9 = bits 0 and 3 [build];
+                                   env VKRT_WF_SHARE_FLAGS */
   VKRT_OPT_GBUFFER_MIPS    = 9, /* NOT a scheduling knob: 1 (default) = vkrt_gbuffer_raycast samples textures like the fragment shader it replaces
                                    (implicit LOD over the mip chain, anisotropy 4; hello_vulkan.cpp:448-454, :499), 0 = LOD 0; env VKRT_GBUFFER_MIPS */
   VKRT_OPT_WATERTIGHT      = 10, /* NOT a scheduling knob [build]: 0 (default) = Moeller-Trumbore on pre-subtracted (v0, e1, e2) records in binary32

@@ -723,7 +723,7 @@ def test_scene_options_are_per_handle_and_do_not_change_pixels(atrium_small):
     W, H = 384, 216
     cam = default_camera(W, H, **camkw)
     variants = [{}, {abi.VKRT_OPT_WF_SUBFRAMES: 1}, {abi.VKRT_OPT_WF_SUBFRAMES: 2}, {abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 0},
-                {abi.VKRT_OPT_WF_SHARE: 4, abi.VKRT_OPT_WF_SHARE_FLAGS: 1}, {abi.VKRT_OPT_WF_TRAV_BLOCK: 256}, {abi.VKRT_OPT_BVH_LAYOUT: 0},
+                {abi.VKRT_OPT_WF_SHARE: 4, abi.VKRT_OPT_WF_SHARE_FLAGS: 1}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 2}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 5}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 12}, {abi.VKRT_OPT_WF_TRAV_BLOCK: 256}, {abi.VKRT_OPT_BVH_LAYOUT: 0},
                 {abi.VKRT_OPT_TRI_THRESHOLD: 0, abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_MODE: 0}]
     rs = [Renderer(flat, device=0, build="sah", options=v) for v in variants]
     assert rs[1].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 1 and rs[0].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 3

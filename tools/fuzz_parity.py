@@ -175,6 +175,7 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
     if rng.random() < 0.2: opts[abi.VKRT_OPT_WF_SUBFRAMES] = int(rng.integers(1, 5))
     if rng3.random() < 0.2: opts[abi.VKRT_OPT_WATERTIGHT] = 1               # the other triangle test, on both sides
     if rng3.random() < 0.2: opts[abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS] = 1    # must not change a pixel
+    if rng3.random() < 0.3: opts[abi.VKRT_OPT_WF_SHARE_FLAGS] = int(rng3.integers(0, 16))  # child donation and the order rules of any-hit walks on and off
     if rng3.random() < 0.15:                                                 # the any-hit alpha / dissolve stage, with non-opaque materials
         opts[abi.VKRT_OPT_ANYHIT_DISSOLVE] = 1
         for m in flat.materials:

@@ -94,6 +94,7 @@ struct DevScene
   uint32_t gbufferMips;       // hybrid G-buffer: 1 = implicit-LOD texture() as in a fragment shader (trilinear + 4x anisotropy), 0 = LOD 0
   uint32_t shareFlags;        // bit 0: lanes whose stack is empty also donate the farthest pending child of their current group
   uint32_t watertight;        // 1: triangle records hold (p0, p1, p2) and the kernels run the watertight test (VKRT_OPT_WATERTIGHT)
+  float sceneLo[3], sceneHi[3];  // world-space bounds of the instanced geometry (conservative; read by the any-hit order heuristic only)
   uint32_t dissolve;          // 1: any-hit alpha / dissolve stage (VKRT_OPT_ANYHIT_DISSOLVE): bit 31 of a record's id word flags a non-opaque triangle
   unsigned long long* faults; // sticky tally of dropped stack pushes + step-limit exits (a walk that was cut short); must stay 0
 };

@@ -60,6 +60,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
   const int lane = (int)lane_id();
   const unsigned shareMin = sc.shareMinIdle;
   const unsigned long long below = (1ull << lane) - 1ull;
+  bool farFirst = ANYHIT && anyhit_far_first(sc, o, d, tmax);  // child order of this lane's ray (traverse.h)
 
   res.key[lane] = ((unsigned long long)__float_as_uint(tmax) << 32) | 0xffffffffull;
   res.slot[lane] = -1; res.u[lane] = 0.0f; res.v[lane] = 0.0f;
@@ -104,7 +105,9 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           }
           else
           {
-            const unsigned top = G.y & 0xff000000u, low = top & (0u - top);  // lowest pending bit = last in front-to-back order
+            const unsigned top = G.y & 0xff000000u;
+            // the child this lane would visit LAST: the lowest pending bit in front-to-back order, the highest with farFirst
+            const unsigned low = farFirst ? (0x80000000u >> (unsigned)__clz((int)top)) : (top & (0u - top));
             e = make_uint2(G.x, low | (G.y & 0xffu));
             G.y &= ~low;
           }
@@ -127,6 +130,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
         {
           o = mk3(ox, oy, oz); d = mk3(dx, dy, dz); id = mk3(ix, iy, iz); tmax = tm;
           tr.set(d);  // (watertight: the adopted ray's shear constants, recomputed rather than shuffled)
+          farFirst = ANYHIT && anyhit_far_first(sc, o, d, tmax);
           px = !(id.x < 0.0f); py = !(id.y < 0.0f); pz = !(id.z < 0.0f);
           octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
           G = make_uint2(ex, ey);
@@ -253,7 +257,8 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
         };
         if(G.y & 0xff000000u)
         {
-          const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
+          // closest-hit walks go front to back; any-hit walks take the FARTHEST pending child first (farFirst): see anyhit_far_first
+          const unsigned bitIdx = farFirst ? (unsigned)__ffs((int)(G.y & 0xff000000u)) - 1u : 31u - (unsigned)__clz((int)G.y);
           const unsigned slot = (bitIdx - 24u) ^ octinv;
           const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
           G.y &= ~(1u << bitIdx);

@@ -26,6 +26,7 @@ struct W8State
 {
   TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> tr;
   uint32_t raySeed;
+  bool farFirst;
   f3 o, d, id;
   float tmax, bestT, bestU, bestV;
   int bestSlot, bestGid;
@@ -41,6 +42,7 @@ VKRT_DEV void w8_begin(const DevScene& sc, W8State<TM>& S, f3 o, f3 d, float tma
   S.o = o; S.d = d;
   S.tr.set(d);
   S.raySeed = raySeed;
+  S.farFirst = anyHit && anyhit_far_first(sc, o, d, tmax);
   S.id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   S.tmax = tmax; S.bestT = tmax; S.bestU = 0.0f; S.bestV = 0.0f;
   S.bestSlot = -1; S.bestGid = -1;
@@ -137,8 +139,8 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<TM>& S, float tmin, uint2* 
   uint2 T = make_uint2(0u, 0u);
   if(G.y & 0xff000000u)
   {
-    // take the nearest pending internal child of the group
-    const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
+    // take the nearest pending internal child of the group (any-hit walks: the farthest, traverse.h anyhit_far_first)
+    const unsigned bitIdx = (ANYHIT && S.farFirst) ? (unsigned)__ffs((int)(G.y & 0xff000000u)) - 1u : 31u - (unsigned)__clz((int)G.y);
     const unsigned slot = (bitIdx - 24u) ^ octinv;
     const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
     G.y &= ~(1u << bitIdx);
@@ -229,6 +231,7 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
 {
   TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> tr;
   tr.set(d);
+  const bool farFirst = ANYHIT && anyhit_far_first(sc, o, d, tmax);
   const float4* __restrict__ nodes = sc.nodes;
   const float4* __restrict__ tris = sc.tris;
   const int cap = (int)(sc.stackCap >> 1);
@@ -285,8 +288,8 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
   {
     if(G.y & 0xff000000u)
     {
-      // nearest pending internal child of the group; the rest of the group waits on the stack
-      const unsigned bitIdx = 31u - (unsigned)__clz((int)G.y);
+      // nearest pending internal child of the group (any-hit walks: the farthest); the rest of the group waits on the stack
+      const unsigned bitIdx = farFirst ? (unsigned)__ffs((int)(G.y & 0xff000000u)) - 1u : 31u - (unsigned)__clz((int)G.y);
       const unsigned slot = (bitIdx - 24u) ^ octinv;
       const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
       G.y &= ~(1u << bitIdx);

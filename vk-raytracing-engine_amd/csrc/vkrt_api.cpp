@@ -22,7 +22,7 @@
 
 #define VKRT_TRI_THRESHOLD_DEFAULT 1
 #define VKRT_WF_SHARE_DEFAULT 16
-#define VKRT_WF_SHARE_FLAGS_DEFAULT 1
+#define VKRT_WF_SHARE_FLAGS_DEFAULT 9
 #include "lbvh.h"
 
 namespace {
@@ -83,6 +83,7 @@ struct vkrt_scene
   bool wfTimed = false;
   // execution options (include/vkrt.h vkrt_option); index = option id
   int opt[VKRT_OPT_LAST + 1] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1, 0, 0, 0};
+  bool hasLargeTriangles = false;  // some instanced triangle covers more than 1 % of the largest face of the scene's box (any-hit order heuristic)
   bool wavefront = true;  // execution mode the acceleration structure was built for (opt[VKRT_OPT_MODE] at vkrt_accel_build)
 };
 
@@ -201,7 +202,7 @@ int clampOption(int option, int v)
     case VKRT_OPT_WF_SHARE: return std::max(0, std::min(64, v));
     case VKRT_OPT_TRI_THRESHOLD: return std::max(0, std::min(65, v));
     case VKRT_OPT_WF_SHARE_PERIOD: return std::max(0, std::min(255, v));
-    case VKRT_OPT_WF_SHARE_FLAGS: return v & 1;
+    case VKRT_OPT_WF_SHARE_FLAGS: return v & 15;
     case VKRT_OPT_GBUFFER_MIPS: case VKRT_OPT_WATERTIGHT: case VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: case VKRT_OPT_ANYHIT_DISSOLVE: return v ? 1 : 0;
   }
   return v;
@@ -713,11 +714,77 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
       s->info.triangle_bytes = (uint64_t)r.triCount * 48;
     }
   }
+  // world-space bounds of the instanced geometry, conservatively from the corners of every node's local box (the any-hit order
+  // heuristic asks whether a ray ends outside them; nothing else reads them)
+  {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    std::vector<float> meshBox(s->primMeshes.size() * 6);
+    for(size_t m = 0; m < s->primMeshes.size(); m++)
+    {
+      const vkrt_prim_mesh& pm = s->primMeshes[m];
+      float* b = &meshBox[m * 6];
+      for(int k = 0; k < 3; k++) { b[k] = INFINITY; b[3 + k] = -INFINITY; }
+      for(uint32_t v = 0; v < pm.vertexCount; v++)
+        for(int k = 0; k < 3; k++)
+        {
+          const float x = s->positions[3 * (size_t)(pm.vertexOffset + v) + k];
+          b[k] = std::min(b[k], x); b[3 + k] = std::max(b[3 + k], x);
+        }
+    }
+    for(const vkrt_node& n : s->nodes)
+    {
+      const float* b = &meshBox[(size_t)n.primMesh * 6];
+      if(!(b[0] <= b[3]))
+        continue;
+      for(int c = 0; c < 8; c++)
+      {
+        const float p[3] = {(c & 1) ? b[3] : b[0], (c & 2) ? b[4] : b[1], (c & 4) ? b[5] : b[2]};
+        for(int k = 0; k < 3; k++)
+        {
+          const float w = n.worldMatrix[k] * p[0] + n.worldMatrix[4 + k] * p[1] + n.worldMatrix[8 + k] * p[2] + n.worldMatrix[12 + k];
+          lo[k] = std::min(lo[k], w); hi[k] = std::max(hi[k], w);
+        }
+      }
+    }
+    for(int k = 0; k < 3; k++)
+    {
+      const float pad = 1e-3f * std::max(1e-6f, hi[k] - lo[k]);
+      s->dev.sceneLo[k] = lo[k] - pad; s->dev.sceneHi[k] = hi[k] + pad;
+    }
+    // "large" = a triangle of more than 1 % of the largest face of the scene's box (world space, every instance)
+    const double ex = (double)hi[0] - lo[0], ey = (double)hi[1] - lo[1], ez = (double)hi[2] - lo[2];
+    const double face = std::max(ex * ey, std::max(ey * ez, ez * ex));
+    double maxArea = 0.0;
+    for(const vkrt_node& n : s->nodes)
+    {
+      const vkrt_prim_mesh& pm = s->primMeshes[(size_t)n.primMesh];
+      const float* M = n.worldMatrix;
+      for(uint32_t t = 0; t + 3 <= pm.indexCount; t += 3)
+      {
+        double w[3][3];
+        for(int v = 0; v < 3; v++)
+        {
+          const float* p = &s->positions[3 * (size_t)(s->indices[pm.firstIndex + t + v] + pm.vertexOffset)];
+          for(int k = 0; k < 3; k++) w[v][k] = (double)M[k] * p[0] + (double)M[4 + k] * p[1] + (double)M[8 + k] * p[2] + (double)M[12 + k];
+        }
+        const double a[3] = {w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2]}, b[3] = {w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2]};
+        const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+        maxArea = std::max(maxArea, 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz));
+      }
+    }
+    s->hasLargeTriangles = face > 0.0 && maxArea > 0.01 * face;
+  }
   s->dev.stepLimit = 4u * (s->info.node_count + s->info.triangle_count) + 64u;
   s->dev.triThreshold = 0;
   s->dev.shareMinIdle = 0;
   s->dev.sharePeriodMask = 0;
-  s->dev.shareFlags = 0;
+  // order of any-hit walks (bits 1, 2: every layout and mode; traverse.h anyhit_far_first).  Bit 3 = automatic: far-first for rays that
+  // end outside the scene bounds unless the scene has LARGE triangles -- room-sized polygons sit in the leaves of the top nodes and
+  // stop such rays within a step or two of a front-to-back walk, which the far-first order then only delays (measured on the two
+  // tessellations of the atrium, profiles/r03_experiments.md #94: +3.3 % on the uniform one, -2 % on the Sponza-like one)
+  s->dev.shareFlags = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 6u;
+  if((s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 8) && !s->hasLargeTriangles)
+    s->dev.shareFlags |= 4u;
   if(s->dev.layout == 1)
   {
     // triangle postponing (traverse_wide.h): lanes with pending triangles before a wave tests them; 0 = immediate
@@ -727,7 +794,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     // work sharing inside a traversal wave (traverse_share.h): minimum number of idle lanes before they take over subtrees
     s->dev.shareMinIdle = (uint32_t)s->opt[VKRT_OPT_WF_SHARE];
     s->dev.sharePeriodMask = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_PERIOD];
-    s->dev.shareFlags = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS];
+    s->dev.shareFlags |= (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 1u;
   }
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
   if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)
