@@ -7,6 +7,7 @@
 // device_scene.h, nodes in depth-first order (a node's first child is usually the next line).
 #include "bvh_host.h"
 #include "tri_prep.h"
+#include "wide_node.h"
 
 #include <algorithm>
 #include <cmath>
@@ -496,26 +497,27 @@ struct W8Ctx
       slotOf[bc] = bs;
       childAt[bs] = bc;
     }
-    // grid: origin = lo, per-axis power-of-two cell so that the extent fits 255 cells
+    // grid: origin = lo, per-axis power-of-two cell so that the extent fits QMAX cells
+    const int QMAX = VKRT_WNODE_QMAX;
     uint32_t eb[3];
     for(int k = 0; k < 3; k++)
     {
       const double ext = (double)hi[k] - (double)lo[k];
-      int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+      int e = ext > 0 ? (int)std::ceil(std::log2(ext / (double)QMAX)) : -126;
       e = std::min(std::max(e, -126), 126);
       for(;;)
       {  // make sure every child's hi really fits (ceil may need one more cell)
         const double sc = std::ldexp(1.0, e);
         bool ok = true;
         for(const W8Child& c : kids)
-          if(std::ceil(((double)c.hi[k] - (double)lo[k]) / sc) > 255.0) ok = false;
+          if(std::ceil(((double)c.hi[k] - (double)lo[k]) / sc) > (double)QMAX) ok = false;
         if(ok || e >= 126) break;
         e++;
       }
       eb[k] = (uint32_t)(e + 127);
     }
     uint32_t imask = 0, meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint8_t qlo[3][8], qhi[3][8];
+    uint16_t qlo[3][8], qhi[3][8];
     memset(qlo, 0, sizeof qlo);
     memset(qhi, 0, sizeof qhi);
     const uint32_t triBase = (uint32_t)out.triOrder.size();
@@ -531,13 +533,13 @@ struct W8Ctx
       {
         const double sc = std::ldexp(1.0, (int)eb[k] - 127), o = (double)lo[k];
         int ql = (int)std::floor(((double)ch.lo[k] - o) / sc);
-        ql = std::min(std::max(ql, 0), 255);
+        ql = std::min(std::max(ql, 0), QMAX);
         while(ql > 0 && o + ql * sc > (double)ch.lo[k]) ql--;
         int qh = (int)std::ceil(((double)ch.hi[k] - o) / sc);
-        qh = std::min(std::max(qh, 0), 255);
-        while(qh < 255 && o + qh * sc < (double)ch.hi[k]) qh++;
-        qlo[k][s] = (uint8_t)ql;
-        qhi[k][s] = (uint8_t)qh;
+        qh = std::min(std::max(qh, 0), QMAX);
+        while(qh < QMAX && o + qh * sc < (double)ch.hi[k]) qh++;
+        qlo[k][s] = (uint16_t)ql;
+        qhi[k][s] = (uint16_t)qh;
       }
       if(!isLeafChild(ch))
       {
@@ -557,19 +559,16 @@ struct W8Ctx
       }
     }
     sahSum += (double)boxAreaF(lo, hi) * kNodeCost;  // one node visit
-    const uint32_t childBase = (uint32_t)(out.nodes.size() / 20);
-    out.nodes.resize(out.nodes.size() + 20 * internalSlots.size());
-    uint32_t* n = &out.nodes[(size_t)me * 20];
+    const uint32_t childBase = (uint32_t)(out.nodes.size() / VKRT_WNODE_DWORDS);
+    out.nodes.resize(out.nodes.size() + VKRT_WNODE_DWORDS * internalSlots.size());
+    uint32_t* n = &out.nodes[(size_t)me * VKRT_WNODE_DWORDS];
     memcpy(&n[0], &lo[0], 4); memcpy(&n[1], &lo[1], 4); memcpy(&n[2], &lo[2], 4);
     n[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24);
     n[4] = childBase;
     n[5] = triBase;
     n[6] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | (meta[3] << 24);
     n[7] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24);
-    auto pack4 = [](const uint8_t* q) { return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
-    n[8] = pack4(&qlo[0][0]); n[9] = pack4(&qlo[0][4]); n[10] = pack4(&qlo[1][0]); n[11] = pack4(&qlo[1][4]);
-    n[12] = pack4(&qlo[2][0]); n[13] = pack4(&qlo[2][4]); n[14] = pack4(&qhi[0][0]); n[15] = pack4(&qhi[0][4]);
-    n[16] = pack4(&qhi[1][0]); n[17] = pack4(&qhi[1][4]); n[18] = pack4(&qhi[2][0]); n[19] = pack4(&qhi[2][4]);
+    vkrt_wnode_store_planes(n, qlo, qhi);
     // recurse (internalSlots is in increasing slot order = storage order)
     for(size_t k = 0; k < internalSlots.size(); k++)
     {
@@ -604,7 +603,7 @@ void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltW
     return;
   W8Ctx cx{b2, out};
   out.triOrder.reserve(tris.size());
-  out.nodes.resize(20);
+  out.nodes.resize(VKRT_WNODE_DWORDS);
   std::vector<W8Child> kids;
   if(b2.rootRef < 0)
   {  // single triangle: a root with one leaf child
@@ -641,7 +640,7 @@ void collapse_wide8(const BuiltBvh& b2, const std::vector<FlatTri>& tris, BuiltW
     cx.rootArea = std::max(boxAreaF(lo, hi), 1e-30f);
   }
   cx.emit(0, kids, 0);
-  out.nodeCount = (uint32_t)(out.nodes.size() / 20);
+  out.nodeCount = (uint32_t)(out.nodes.size() / VKRT_WNODE_DWORDS);
   out.sahCost = (float)(cx.sahSum / cx.rootArea);
 }
 

@@ -49,7 +49,7 @@ VKRT_DEV ShareRes shareRes(int* lds320)
 // stk: this lane's stack column (stride 64 entries), res: the wave's ShareRes block.
 template <bool COUNT, bool ANYHIT, int TM = 0>
 VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, uint2* stk, ShareRes res, RayHit& hit,
-                                   TravCount& tc, uint32_t raySeed = 0u)
+                                   TravCount& tc, uint32_t raySeed = 0u, vkrt_lds_float4* topLds = nullptr)
 {
   TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> tr;
   tr.set(d);
@@ -273,7 +273,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
               VKRT_TRAV_FAULT(sc);
           }
           uint2 Tn;
-          w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bt, G, Tn, tc);
+          w8_test_children<COUNT, VKRT_TOP_NODES>(nodes, child, o, id, octinv, px, py, pz, tmin, bt, G, Tn, tc, topLds);
           if(Tn.y != 0u)
           {
             if(T.y != 0u)

@@ -19,6 +19,7 @@
 #include "bvh_host.h"
 #include "device_scene.h"
 #include "kernels.h"
+#include "wide_node.h"
 
 #define VKRT_TRI_THRESHOLD_DEFAULT 1
 #define VKRT_WF_SHARE_DEFAULT 16
@@ -572,7 +573,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     if(!shadeRec.empty())
       HIP_TRY(hipMemcpyAsync(s->accelShade, shadeRec.data(), shadeRec.size() * 4, hipMemcpyHostToDevice, stream));
     s->dev.triShade = (const uint4*)s->accelShade;
-    const size_t nodeBytes = std::max<size_t>(nodeBytesUsed, 80);
+    const size_t nodeBytes = std::max<size_t>(nodeBytesUsed, VKRT_WNODE_MIN_ALLOC);
     const size_t triBytes = std::max<size_t>(packed.size() * sizeof(float), 48);
     HIP_TRY(hipMalloc(&s->accelNodes, nodeBytes));
     HIP_TRY(hipMalloc(&s->accelTris, triBytes));
@@ -634,7 +635,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
       s->info.node_count = r.wide.nodeCount;
       s->info.max_depth = r.wide.maxDepth;
       s->info.sah_cost = r.wide.sahCost;
-      s->info.node_bytes = (uint64_t)r.wide.nodeCount * 80;
+      s->info.node_bytes = (uint64_t)r.wide.nodeCount * VKRT_WNODE_BYTES;
       s->info.triangle_bytes = (uint64_t)r.triCount * 48;
     }
     else if(wide && r.triCount > 0)
@@ -678,7 +679,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
       std::vector<uint32_t> shadeRec;
       vkrt::pack_triangles(tris, w8.triOrder, packed, watertight, dissolvePtr);
       vkrt::pack_tri_shade(tris, w8.triOrder, s->indices.data(), s->primMeshes.data(), s->nodes.data(), shadeRec);
-      HIP_TRY(hipMalloc(&s->accelNodes, std::max<size_t>(w8.nodes.size() * 4, 80)));
+      HIP_TRY(hipMalloc(&s->accelNodes, std::max<size_t>(w8.nodes.size() * 4, VKRT_WNODE_MIN_ALLOC)));
       HIP_TRY(hipMalloc(&s->accelTris, std::max<size_t>(packed.size() * 4, 48)));
       HIP_TRY(hipMalloc(&s->accelShade, std::max<size_t>(shadeRec.size() * 4, 16)));
       HIP_TRY(hipMemcpy(s->accelNodes, w8.nodes.data(), w8.nodes.size() * 4, hipMemcpyHostToDevice));

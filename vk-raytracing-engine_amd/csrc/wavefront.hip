@@ -283,10 +283,17 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(TM != 0 && W
   {
     // the whole wave walks together: lanes past the end of the stream have no ray of their own but help
     uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
+    vkrt_lds_float4* topLds = nullptr;
+#if VKRT_TOP_NODES > 0
+    __shared__ float4 topNodes[VKRT_TOP_NODES * VKRT_WNODE_QUADS];
+    for(unsigned k = threadIdx.x; k < VKRT_TOP_NODES * VKRT_WNODE_QUADS; k += 64u) topNodes[k] = P.sc.nodes[k];
+    shareSync();
+    topLds = (vkrt_lds_float4*)topNodes;
+#endif
     if(anyHit)
-      traverse_wide8_share<COUNT, true, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
+      traverse_wide8_share<COUNT, true, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed, topLds);
     else
-      traverse_wide8_share<COUNT, false, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
+      traverse_wide8_share<COUNT, false, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed, topLds);
     if(valid)
       storeHit(P, B, par, kind, qi, hit);
   }

@@ -25,6 +25,7 @@
 
 #include "device_math.h"
 #include "lbvh.h"
+#include "wide_node.h"
 
 namespace vkrt {
 
@@ -157,7 +158,7 @@ struct Emit
   uint32_t* level;    // [0] start of the current level, [1] its node count, [2] triangles emitted so far, [3] levels done,
                       // [4] overflow flag; [8 + 2 L], [9 + 2 L]: start / count of level L (for the caller's statistics)
   uint32_t* triOrder; // wide-tree slot -> position in the LBVH's sorted triangle arrays
-  uint4* outNodes;    // 5 x uint4 per wide node
+  uint4* outNodes;    // VKRT_WNODE_QUADS x uint4 per wide node
   float* nodeCost;    // SAH contribution per wide node
   uint32_t capacity;  // wide nodes the arrays can hold
   uint32_t triCount;
@@ -344,7 +345,8 @@ __global__ void k_w8_write(Emit E, uint32_t lvl)
     slotOf[bc] = bs;
     childAt[bs] = bc;
   }
-  // grid: origin = lo, per-axis power-of-two cell so that the extent fits 255 cells
+  // grid: origin = lo, per-axis power-of-two cell so that the extent fits QMAX cells
+  const int QMAX = VKRT_WNODE_QMAX;
   uint32_t eb[3];
   for(int q = 0; q < 3; q++)
   {
@@ -353,7 +355,7 @@ __global__ void k_w8_write(Emit E, uint32_t lvl)
     if(ext > 0)
     {
       int ex;
-      const double m = frexp(ext / 255.0, &ex);  // ext / 255 = m 2^ex, m in [0.5, 1): ceil(log2) = ex, or ex - 1 for an exact power of two
+      const double m = frexp(ext / (double)QMAX, &ex);  // ext / QMAX = m 2^ex, m in [0.5, 1): ceil(log2) = ex, or ex - 1 for an exact power of two
       e = m == 0.5 ? ex - 1 : ex;
     }
     e = e < -126 ? -126 : (e > 126 ? 126 : e);
@@ -362,14 +364,16 @@ __global__ void k_w8_write(Emit E, uint32_t lvl)
       const double sc = ldexp(1.0, e);
       bool ok = true;
       for(int k = 0; k < n; k++)
-        if(ceil(((double)kids[k].hi[q] - (double)lo[q]) / sc) > 255.0) ok = false;
+        if(ceil(((double)kids[k].hi[q] - (double)lo[q]) / sc) > (double)QMAX) ok = false;
       if(ok || e >= 126) break;
       e++;
     }
     eb[q] = (uint32_t)(e + 127);
   }
   uint32_t imask = 0, meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t qlo[3][2] = {{0, 0}, {0, 0}, {0, 0}}, qhi[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+  uint16_t qlo[3][8], qhi[3][8];
+  for(int q = 0; q < 3; q++)
+    for(int s = 0; s < 8; s++) { qlo[q][s] = 0; qhi[q][s] = 0; }
   const uint32_t triBase = E.baseT[me], childBase = E.baseI[me];
   uint32_t triOff = 0, nInternal = 0;
   double sah = (double)areaOf(lo, hi) * kNodeCost;
@@ -383,13 +387,13 @@ __global__ void k_w8_write(Emit E, uint32_t lvl)
     {
       const double sc = ldexp(1.0, (int)eb[q] - 127), o = (double)lo[q];
       int ql = (int)floor(((double)ch.lo[q] - o) / sc);
-      ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+      ql = ql < 0 ? 0 : (ql > QMAX ? QMAX : ql);
       while(ql > 0 && o + ql * sc > (double)ch.lo[q]) ql--;
       int qh = (int)ceil(((double)ch.hi[q] - o) / sc);
-      qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
-      while(qh < 255 && o + qh * sc < (double)ch.hi[q]) qh++;
-      qlo[q][s >> 2] |= (uint32_t)ql << (8 * (s & 3));
-      qhi[q][s >> 2] |= (uint32_t)qh << (8 * (s & 3));
+      qh = qh < 0 ? 0 : (qh > QMAX ? QMAX : qh);
+      while(qh < QMAX && o + qh * sc < (double)ch.hi[q]) qh++;
+      qlo[q][s] = (uint16_t)ql;
+      qhi[q][s] = (uint16_t)qh;
     }
     if(!((leafMask >> c) & 1u))
     {
@@ -419,12 +423,14 @@ __global__ void k_w8_write(Emit E, uint32_t lvl)
       k2++;
     }
   (void)nInternal;
-  uint4* nd = E.outNodes + (size_t)me * 5;
-  nd[0] = make_uint4(__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(lo[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24));
-  nd[1] = make_uint4(childBase, triBase, meta[0] | (meta[1] << 8) | (meta[2] << 16) | (meta[3] << 24), meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24));
-  nd[2] = make_uint4(qlo[0][0], qlo[0][1], qlo[1][0], qlo[1][1]);
-  nd[3] = make_uint4(qlo[2][0], qlo[2][1], qhi[0][0], qhi[0][1]);
-  nd[4] = make_uint4(qhi[1][0], qhi[1][1], qhi[2][0], qhi[2][1]);
+  uint32_t w[VKRT_WNODE_DWORDS];
+  w[0] = __float_as_uint(lo[0]); w[1] = __float_as_uint(lo[1]); w[2] = __float_as_uint(lo[2]); w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24);
+  w[4] = childBase; w[5] = triBase;
+  w[6] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | (meta[3] << 24);
+  w[7] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | (meta[7] << 24);
+  vkrt_wnode_store_planes(w, qlo, qhi);
+  uint4* nd = E.outNodes + (size_t)me * VKRT_WNODE_QUADS;
+  for(int k = 0; k < VKRT_WNODE_QUADS; k++) nd[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
   E.nodeCost[me] = (float)sah;
 }
 
@@ -520,7 +526,7 @@ int collapse_wide8_device(const WideCollapseIn& in, hipStream_t stream, WideColl
   WC_TRY(alloc((void**)&E.triOrder, (size_t)T * 4));
   WC_TRY(alloc((void**)&E.nodeCost, (size_t)cap * 4));
   WC_TRY(alloc((void**)&stats, 16));
-  WC_TRY(hipMalloc(&out.nodes, std::max<size_t>((size_t)cap * 80, 80)));
+  WC_TRY(hipMalloc(&out.nodes, std::max<size_t>((size_t)cap * VKRT_WNODE_BYTES, VKRT_WNODE_MIN_ALLOC)));
   WC_TRY(hipMalloc(&out.tris, (size_t)T * 48));
   WC_TRY(hipMalloc(&out.triShade, (size_t)T * 16));
   E.nodes2 = in.nodes2;
