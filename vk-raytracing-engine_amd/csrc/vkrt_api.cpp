@@ -797,6 +797,10 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     s->dev.sharePeriodMask = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_PERIOD];
     s->dev.shareFlags |= (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 1u;
   }
+#if defined(VKRT_EXP) && VKRT_EXP == 10
+  if(const char* e = getenv("VKRT_STACK_CAP_WORDS"))  // experiment #99: a smaller stack frees LDS for a sixth wave per SIMD (overflows are counted as faults)
+    s->dev.stackCap = (uint32_t)atoi(e);
+#endif
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
   if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)
     return fail(VKRT_ERR_UNSUPPORTED, "BVH depth %u needs a %zu-byte LDS stack per workgroup (limit 64 KiB)", s->info.max_depth,

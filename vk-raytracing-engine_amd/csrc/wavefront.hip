@@ -236,7 +236,13 @@ VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int ki
 
 // ---- traversal: one thread per queued ray, workgroups homogeneous in ray kind -----------------------------------
 template <bool COUNT, bool WIDE, int TB, int TM = 0>
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(TM != 0 && WIDE && TB == 64 ? 5 : 1))) void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
+__global__ __launch_bounds__(TB)
+#if defined(VKRT_EXP) && VKRT_EXP == 10
+__attribute__((amdgpu_waves_per_eu(WIDE && TB == 64 ? (TM != 0 ? 5 : 6) : 1)))  // experiment #99: six waves per SIMD (80 VGPRs + 16 B of scratch)
+#else
+__attribute__((amdgpu_waves_per_eu(TM != 0 && WIDE && TB == 64 ? 5 : 1)))
+#endif
+void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
 {
   extern __shared__ int lds_stack[];
   const int par = round & 1;
