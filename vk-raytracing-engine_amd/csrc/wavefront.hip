@@ -599,6 +599,12 @@ static void launchTraverse(const TraceParams& P, const WfBuffers& B, int r, unsi
   const bool wide = P.sc.layout == 1u;
   const int tm = (P.sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (P.sc.dissolve ? VKRT_TM_DISSOLVE : 0);
   const dim3 tb(travBlock);
+#if defined(VKRT_EXP) && VKRT_EXP == 11
+  // experiment #100: pad the traversal workgroup's LDS so that fewer of them fit a CU and the shade waves of the other sub-frames
+  // (142 VGPRs) find register room beside them
+  static const size_t ldsPad = getenv("VKRT_TRAV_LDS_PAD") ? (size_t)atoi(getenv("VKRT_TRAV_LDS_PAD")) : 0;
+  tlds += ldsPad;
+#endif
 #define VKRT_TRAV_LAUNCH(C, W, TB, TM) hipLaunchKernelGGL((k_wf_traverse<C, W, TB, TM>), tg, tb, tlds, stream, P, B, r)
 #define VKRT_TRAV_MODES(TB, TM)                                                                                                        \
   do {                                                                                                                                 \
