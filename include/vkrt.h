@@ -226,7 +226,9 @@ enum vkrt_option {
                                    decision here is a pure function of the ray and the triangle: rnd(tea(triangle id, prd.seed when the ray is traced)) >
                                    dissolve; prd.seed itself is not advanced.  The result stays a property of the triangle set (any tree, any schedule);
                                    the oracle implements the same rule (orc_set_dissolve).  env VKRT_ANYHIT_DISSOLVE */
-  VKRT_OPT_LAST            = 12
+  VKRT_OPT_LAST            = 12,
+  VKRT_INFO_ANYHIT_ORDER   = 100 /* read-only (vkrt_scene_get_option; set is refused): the child-order bits (2 | 4) that the last vkrt_accel_build
+                                   resolved VKRT_OPT_WF_SHARE_FLAGS to, i.e. what bit 3 ("automatic") decided for this scene; 0 before a build */
 };
 int vkrt_scene_set_option(vkrt_scene* scene, int option, int value);
 int vkrt_scene_get_option(const vkrt_scene* scene, int option, int* value);

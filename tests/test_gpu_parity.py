@@ -747,6 +747,34 @@ def test_scene_options_are_per_handle_and_do_not_change_pixels(atrium_small):
 
 
 @pytest.mark.gpu
+def test_anyhit_child_order_is_resolved_per_scene(cornell_flat):
+    """VKRT_OPT_WF_SHARE_FLAGS bit 3 (the default) picks the child order of shadow / AO walks at the build: farthest first for rays
+    that end outside the scene (bit 2) on finely tessellated geometry, front to back where room-sized triangles exist (the Cornell
+    box: two triangles per wall).  Bits 1 / 2 force an order; the resolved bits are readable, not settable."""
+    import os, sys
+
+    from vkrt_amd import abi
+    from vkrt_amd.renderer import Renderer, VkrtError
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import atrium
+
+    flat, _ = atrium.build_atrium(60000, seed=3, with_textures=False)  # largest triangle 0.6 % of the largest face of the scene's box
+    got = {}
+    for name, scene in (("atrium", flat), ("cornell", cornell_flat)):
+        for flags in (None, 1, 3, 5, 13):
+            r = Renderer(scene, device=0, build="ploc", options={} if flags is None else {abi.VKRT_OPT_WF_SHARE_FLAGS: flags})
+            got[name, flags] = r.get_option(abi.VKRT_INFO_ANYHIT_ORDER)
+            if flags is None:
+                assert r.get_option(abi.VKRT_OPT_WF_SHARE_FLAGS) == 9
+                with pytest.raises(VkrtError):
+                    r.set_option(abi.VKRT_INFO_ANYHIT_ORDER, 2)
+            r.close()
+    assert got == {("atrium", None): 4, ("atrium", 1): 0, ("atrium", 3): 2, ("atrium", 5): 4, ("atrium", 13): 4,
+                   ("cornell", None): 0, ("cornell", 1): 0, ("cornell", 3): 2, ("cornell", 5): 4, ("cornell", 13): 4}, got
+
+
+@pytest.mark.gpu
 def test_device_builders_tree_quality_and_degenerate_input(atrium_small):
     """The three builders on one scene: the clustered device tree (ploc.hip) must beat the Morton radix tree's SAH cost and come
     close to the host's binned-SAH tree; every tree holds every triangle exactly once.  A pile of identical triangles

@@ -186,6 +186,7 @@ VKRT_OPT_MODE, VKRT_OPT_BVH_LAYOUT, VKRT_OPT_WF_SUBFRAMES, VKRT_OPT_WF_TRAV_BLOC
 VKRT_OPT_WF_SHARE, VKRT_OPT_TRI_THRESHOLD, VKRT_OPT_WF_SHARE_PERIOD, VKRT_OPT_WF_SHARE_FLAGS = 5, 6, 7, 8
 VKRT_OPT_GBUFFER_MIPS = 9
 VKRT_OPT_WATERTIGHT, VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, VKRT_OPT_ANYHIT_DISSOLVE = 10, 11, 12
+VKRT_INFO_ANYHIT_ORDER = 100  # read-only: what the build resolved the any-hit child order to
 
 # every symbol include/vkrt.h declares (tests check the built library exports them all)
 VKRT_SYMBOLS = [

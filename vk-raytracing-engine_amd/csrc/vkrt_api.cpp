@@ -477,6 +477,11 @@ int vkrt_scene_get_option(const vkrt_scene* s, int option, int* value)
 {
   if(!s || !value)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(option == VKRT_INFO_ANYHIT_ORDER)
+  {
+    *value = s->built ? (int)(s->dev.shareFlags & 6u) : 0;
+    return VKRT_OK;
+  }
   if(option < VKRT_OPT_MODE || option > VKRT_OPT_LAST)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
   *value = s->opt[option];
