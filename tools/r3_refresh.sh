@@ -16,3 +16,4 @@ timeout -k 10 300 python bench.py --variant nonuniform --no-cpu-baseline 2>/dev/
 import json; d=json.load(open('$OUT/bench_nonuniform.json')); print('nonuniform', d['value'], d['ms_per_step'], {k:v['Mrays_s'] for k,v in d['config']['builds'].items()})" | tee -a $OUT/refresh.log
 timeout -k 10 600 python tools/config_matrix.py --only-tessellation --cpu-rows 12 --out $OUT/tess.json > $OUT/tess.log 2>&1; tail -n 4 $OUT/tess.log | cut -c1-1500 | tee -a $OUT/refresh.log
 timeout -k 10 300 python tools/shard_probe.py 2>/dev/null | tail -n 1 | tee $OUT/shard_probe.jsonl | cut -c1-600 | tee -a $OUT/refresh.log
+timeout -k 10 900 python tools/config_matrix.py --out $OUT/configs.json > $OUT/configs.log 2>&1; tail -n 2 $OUT/configs.log | cut -c1-300 | tee -a $OUT/refresh.log
