@@ -225,9 +225,16 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           T.y &= T.y - 1u;
           const unsigned s = T.x + i;
           const float4* __restrict__ tp = tris + (size_t)s * VKRT_TRI_QUADS;
+#if VKRT_EXP == 18
+          // experiment #104: triangle records (12.6 MB, more than an XCD's L2 holds) fetched non-temporally so that the nodes stay resident
+          const vkrt_v4f na = __builtin_nontemporal_load((const vkrt_v4f*)&tp[0]), nb = __builtin_nontemporal_load((const vkrt_v4f*)&tp[1]),
+                         nc = __builtin_nontemporal_load((const vkrt_v4f*)&tp[2]);
+          const float4 a = make_float4(na.x, na.y, na.z, na.w), b = make_float4(nb.x, nb.y, nb.z, nb.w), c = make_float4(nc.x, nc.y, nc.z, nc.w);
+#else
           const float4 a = tp[0];
           const float4 b = tp[1];
           const float4 c = tp[2];
+#endif
           if(COUNT)
           {
             tc.tris++;

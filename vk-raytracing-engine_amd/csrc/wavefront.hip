@@ -73,6 +73,25 @@ VKRT_DEV float4* plane(const WfBuffers& B, int parity, int type, int k)
 }
 VKRT_DEV unsigned* countOf(const WfBuffers& B, int parity, int type) { return &B.ctrl[parity * 4 + type]; }
 
+// Stream records are written once and read once: the read is their last use, so it is a non-temporal load (the `nt` policy bit) and
+// the record does not displace tree nodes and triangles from L2 / Infinity Cache on its way out: +1.5 % ray rate on the bench scene,
+// +1.8 % on the Sponza-like one.  The stores stay ordinary -- the next kernel reads the records from the caches; written
+// non-temporally they come back from HBM and the frame is 4.5 % slower (profiles/r03_experiments.md #103; EXP 15 / 17 keep that variant).
+VKRT_DEV float4 wfLoad(const float4* p)
+{
+  const vkrt_v4f v = __builtin_nontemporal_load((const vkrt_v4f*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+#if defined(VKRT_EXP) && (VKRT_EXP == 15 || VKRT_EXP == 17)
+VKRT_DEV void wfStore(float4* p, float4 v)
+{
+  const vkrt_v4f w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, (vkrt_v4f*)p);
+}
+#else
+VKRT_DEV void wfStore(float4* p, float4 v) { *p = v; }
+#endif
+
 VKRT_DEV unsigned packFlags(const LaneState& L)
 {
   return (L.prd.depth & 0xffu) | (((unsigned)L.smpl & 0xffffu) << 8) | ((L.prd.isSpecular ? 1u : 0u) << 25);
@@ -81,7 +100,7 @@ VKRT_DEV unsigned packFlags(const LaneState& L)
 // state common to all streams (S0..S2) -> lane
 VKRT_DEV void loadCommon(const TraceParams& P, const WfBuffers& B, int parity, int type, unsigned i, LaneState& L)
 {
-  const float4 s0 = plane(B, parity, type, WF_S0)[i], s1 = plane(B, parity, type, WF_S1)[i], s2 = plane(B, parity, type, WF_S2)[i];
+  const float4 s0 = wfLoad(&plane(B, parity, type, WF_S0)[i]), s1 = wfLoad(&plane(B, parity, type, WF_S1)[i]), s2 = wfLoad(&plane(B, parity, type, WF_S2)[i]);
   const unsigned flags = __float_as_uint(s1.w), pix = __float_as_uint(s2.w);
   L.curWeight = mk3(s0.x, s0.y, s0.z); L.prd.seed = __float_as_uint(s0.w);
   L.hitValue = mk3(s1.x, s1.y, s1.z);
@@ -101,16 +120,16 @@ VKRT_DEV void loadCommon(const TraceParams& P, const WfBuffers& B, int parity, i
 
 VKRT_DEV void storeState(const WfBuffers& B, int parity, int type, unsigned i, const LaneState& L, f3 weight)
 {
-  plane(B, parity, type, WF_S0)[i] = make_float4(weight.x, weight.y, weight.z, __uint_as_float(L.prd.seed));
-  plane(B, parity, type, WF_S1)[i] = make_float4(L.hitValue.x, L.hitValue.y, L.hitValue.z, __uint_as_float(packFlags(L)));
-  plane(B, parity, type, WF_S2)[i] = make_float4(L.hitValues.x, L.hitValues.y, L.hitValues.z, __uint_as_float(L.px | (L.lrow << 16)));
+  wfStore(&plane(B, parity, type, WF_S0)[i], make_float4(weight.x, weight.y, weight.z, __uint_as_float(L.prd.seed)));
+  wfStore(&plane(B, parity, type, WF_S1)[i], make_float4(L.hitValue.x, L.hitValue.y, L.hitValue.z, __uint_as_float(packFlags(L))));
+  wfStore(&plane(B, parity, type, WF_S2)[i], make_float4(L.hitValues.x, L.hitValues.y, L.hitValues.z, __uint_as_float(L.px | (L.lrow << 16))));
 }
 
 // a path whose next ray is the closest-hit ray (rgen:64-75) -> slot i of stream C
 VKRT_DEV void storeClosest(const WfBuffers& B, int parity, unsigned i, const LaneState& L)
 {
-  plane(B, parity, WF_C, WF_R0)[i] = make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, 10000.0f);
-  plane(B, parity, WF_C, WF_R1)[i] = make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f);
+  wfStore(&plane(B, parity, WF_C, WF_R0)[i], make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, 10000.0f));
+  wfStore(&plane(B, parity, WF_C, WF_R1)[i], make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f));
   storeState(B, parity, WF_C, i, L, L.curWeight);
 }
 
@@ -118,12 +137,12 @@ VKRT_DEV void storeClosest(const WfBuffers& B, int parity, unsigned i, const Lan
 // or, with the closest-hit ray of the next segment riding along, of stream P
 VKRT_DEV void storeShadow(const WfBuffers& B, int parity, int type, unsigned i, const LaneState& L, f3 contrib, f3 nextWeight)
 {
-  plane(B, parity, type, WF_R0)[i] = make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, L.prd.lightDist - 0.1f);
-  plane(B, parity, type, WF_R1)[i] = make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, L.prd.lightDist);
+  wfStore(&plane(B, parity, type, WF_R0)[i], make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, L.prd.lightDist - 0.1f));
+  wfStore(&plane(B, parity, type, WF_R1)[i], make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, L.prd.lightDist));
   if(type == WF_P)
-    plane(B, parity, type, WF_R2)[i] = make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f);
+    wfStore(&plane(B, parity, type, WF_R2)[i], make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f));
   storeState(B, parity, type, i, L, nextWeight);
-  plane(B, parity, type, WF_S3)[i] = make_float4(contrib.x, contrib.y, contrib.z, 0.0f);
+  wfStore(&plane(B, parity, type, WF_S3)[i], make_float4(contrib.x, contrib.y, contrib.z, 0.0f));
 }
 
 // Block-aggregated slot assignment in the next round's streams: ballot + popcount inside each wave, wave totals
@@ -209,7 +228,7 @@ enum { WF_K_CLOSEST_C = 0, WF_K_CLOSEST_P = 1, WF_K_SHADOW_S = 2, WF_K_SHADOW_P 
 VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int kind, unsigned qi, const RayHit& hit)
 {
   if(kind == WF_K_SHADOW_S)
-    plane(B, par, WF_S, WF_H0)[qi] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(hit.slot >= 0 ? 0 : -1));
+    wfStore(&plane(B, par, WF_S, WF_H0)[qi], make_float4(0.0f, 0.0f, 0.0f, __int_as_float(hit.slot >= 0 ? 0 : -1)));
   else if(kind == WF_K_SHADOW_P)
     ((float*)&plane(B, par, WF_P, WF_H0)[qi])[0] = __int_as_float(hit.slot >= 0 ? 1 : 0);  // the closest-hit lane of the record owns .yzw
   else
@@ -222,11 +241,11 @@ VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int ki
       // travel with the hit, so the closest-hit shading starts at the vertex / material loads
       const uint4 ts = P.sc.triShade[hit.slot];
       inst = __float_as_int(P.sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
-      plane(B, par, type, WF_H1)[qi] = make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w));
+      wfStore(&plane(B, par, type, WF_H1)[qi], make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w)));
     }
     float* h = (float*)&plane(B, par, type, WF_H0)[qi];
     if(type == WF_C)
-      plane(B, par, WF_C, WF_H0)[qi] = make_float4(hit.t, hit.u, hit.v, __int_as_float(inst));
+      wfStore(&plane(B, par, WF_C, WF_H0)[qi], make_float4(hit.t, hit.u, hit.v, __int_as_float(inst)));
     else
     {
       h[1] = hit.u; h[2] = hit.v; h[3] = __int_as_float(inst);
@@ -273,15 +292,15 @@ void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
   float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
   if(valid)
   {
-    r0 = plane(B, par, type, WF_R0)[qi];
-    r1 = plane(B, par, type, kind == WF_K_CLOSEST_P ? WF_R2 : WF_R1)[qi];
+    r0 = wfLoad(&plane(B, par, type, WF_R0)[qi]);
+    r1 = wfLoad(&plane(B, par, type, kind == WF_K_CLOSEST_P ? WF_R2 : WF_R1)[qi]);
     if(kind == WF_K_CLOSEST_P)
       r0.w = 10000.0f;
   }
   // any-hit stage: the payload's seed when the ray is traced (S0.w: after the shading that produced the ray, raytrace.rgen:64-97)
   uint32_t raySeed = 0u;
   if((TM & VKRT_TM_DISSOLVE) && valid)
-    raySeed = __float_as_uint(plane(B, par, type, WF_S0)[qi].w);
+    raySeed = __float_as_uint(wfLoad(&plane(B, par, type, WF_S0)[qi]).w);
   TravCount tc;
   __shared__ int shareLds[VKRT_SHARE_LDS_WORDS];
   RayHit hit;
@@ -399,18 +418,18 @@ VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const Hybr
   if(qi < count)
   {
     loadCommon(P, B, par, type, qi, L);
-    const float4 h = plane(B, par, type, WF_H0)[qi], t4 = plane(B, par, type, WF_H1)[qi];
-    const float4 rd = plane(B, par, type, PAIR ? WF_R2 : WF_R1)[qi];
+    const float4 h = wfLoad(&plane(B, par, type, WF_H0)[qi]), t4 = wfLoad(&plane(B, par, type, WF_H1)[qi]);
+    const float4 rd = wfLoad(&plane(B, par, type, PAIR ? WF_R2 : WF_R1)[qi]);
     L.prd.rayDirection = mk3(rd.x, rd.y, rd.z);  // direction of the closest-hit ray that was traced
     L.prd.rayOrigin = mk3(0.0f);                 // rchit / rmiss do not read it
     if(PAIR)
     {
       // finish segment k first (rgen:99-116): its shadow ray came back with this record.  S0 holds the weight after it;
       // the segment is never the last of its sample (emission rule below), so advanceSegment only accumulates and steps depth
-      const float4 s3 = plane(B, par, WF_P, WF_S3)[qi];
+      const float4 s3 = wfLoad(&plane(B, par, WF_P, WF_S3)[qi]);
       const bool shadowHit = __float_as_int(h.x) != 0;
       if(HYBRID)
-        (void)advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? plane(B, par, WF_P, WF_R1)[qi].w : 0.0f);
+        (void)advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? wfLoad(&plane(B, par, WF_P, WF_R1)[qi]).w : 0.0f);
       else
         (void)advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
     }
@@ -458,12 +477,12 @@ VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const H
   if(qi < count)
   {
     loadCommon(P, B, par, WF_S, qi, L);  // S0 holds the weight after this segment
-    const float4 h = plane(B, par, WF_S, WF_H0)[qi], s3 = plane(B, par, WF_S, WF_S3)[qi];
+    const float4 h = wfLoad(&plane(B, par, WF_S, WF_H0)[qi]), s3 = wfLoad(&plane(B, par, WF_S, WF_S3)[qi]);
     L.prd.rayOrigin = mk3(0.0f);     // the sample ends here: startSample sets the next ray, or the pixel is stored
     L.prd.rayDirection = mk3(0.0f);
     const bool shadowHit = __float_as_int(h.w) >= 0;
     if(HYBRID)
-      toClosest = advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? plane(B, par, WF_S, WF_R1)[qi].w : 0.0f);
+      toClosest = advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? wfLoad(&plane(B, par, WF_S, WF_R1)[qi]).w : 0.0f);
     else
       toClosest = advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
   }
