@@ -648,7 +648,39 @@ static void launchTraverse(const TraceParams& P, const WfBuffers& B, int r, unsi
 #undef VKRT_TRAV_LAUNCH
 }
 
-static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsigned travBlock, bool count, hipStream_t stream, WfTiming* timing);
+// One sub-frame = the tiles [tileFirst, tileFirst + tileCount) of the shard with their own streams and counts, on one HIP stream.
+// subframeBegin: counts cleared, one closest-ray record per pixel (raytrace.rgen:27-60).
+static hipError_t subframeBegin(const TraceParams& P, const WfBuffers& B, hipStream_t stream)
+{
+  const unsigned work = P.tileCount * 64u;
+  const hipError_t e = hipMemsetAsync(B.ctrl, 0, 64, stream);
+  if(e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL(k_wf_init, dim3((work + WF_BLOCK - 1) / WF_BLOCK), dim3(WF_BLOCK), 0, stream, P, B);
+  return hipSuccess;
+}
+// a sample takes at most depth + 1 rounds: its first closest-hit ray, then one round per further segment (the shadow ray of
+// segment k travels with the closest-hit ray of segment k + 1), then the shadow ray of its last segment
+static int subframeRounds(const TraceParams& P) { return (P.pc.samples <= 0 || P.pc.depth <= 0) ? 0 : P.pc.samples * (P.pc.depth + 1); }
+// round r: traverse the rays of the records, shade the results into the next round's records
+static void subframeRound(const TraceParams& P, const WfBuffers& B, int r, unsigned travBlock, bool count, hipStream_t stream, WfTiming* timing)
+{
+  const unsigned work = P.tileCount * 64u;
+  // every path holds one record and a record at most two rays; +4 blocks for the partial tails of the four ray kinds.
+  // One wavefront per workgroup by default: a finished wave frees its slot and LDS without waiting for three others.
+  const dim3 tg(2 * ((work + travBlock - 1) / travBlock) + 4);
+  const size_t tlds = (size_t)P.sc.stackCap * travBlock * sizeof(int);
+  const bool timed = timing && timing->events && 2 * (timing->used + 1) <= timing->capacity;
+  if(timed)
+    (void)hipEventRecord(timing->events[2 * timing->used], stream);
+  launchTraverse(P, B, r, travBlock, count, tg, tlds, stream);
+  if(timed)
+  {
+    (void)hipEventRecord(timing->events[2 * timing->used + 1], stream);
+    timing->used++;
+  }
+  hipLaunchKernelGGL(k_wf_shade, dim3((work + WF_BLOCK - 1) / WF_BLOCK + 3), dim3(WF_BLOCK), 0, stream, P, B, r);
+}
 
 hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, bool count, hipStream_t stream, WfTiming* timing,
                                  const WfAsync* async)
@@ -658,65 +690,42 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const
   // per-kernel timing wants the kernels one after another; tiny frames are not worth splitting
   int n = (timing || !async) ? 1 : std::min(want, async->count);
   n = (int)std::min<uint32_t>((uint32_t)std::max(n, 1), std::max(1u, P.tileCount / 256u));
+  const int rounds = subframeRounds(P);
+  hipError_t e;
   if(n <= 1)
   {
     TraceParams Q = P;
     Q.tileFirst = 0;
-    return launchSubframe(Q, B, travBlock, count, stream, timing);
+    if((e = subframeBegin(Q, B, stream)) != hipSuccess) return e;
+    if(timing)
+      timing->used = 0;
+    for(int r = 0; r < rounds; r++) subframeRound(Q, B, r, travBlock, count, stream, timing);
+    return hipGetLastError();
   }
-  hipError_t e = hipEventRecord(async->fork, stream);
-  if(e != hipSuccess)
-    return e;
+  if((e = hipEventRecord(async->fork, stream)) != hipSuccess) return e;
+  TraceParams Q[VKRT_WF_MAX_SUBFRAMES];
+  WfBuffers Bj[VKRT_WF_MAX_SUBFRAMES];
   for(int j = 0; j < n; j++)
   {
     const uint32_t t0 = (uint32_t)((uint64_t)P.tileCount * j / n), t1 = (uint32_t)((uint64_t)P.tileCount * (j + 1) / n);
-    TraceParams Q = P;
-    Q.tileFirst = t0;
-    Q.tileCount = t1 - t0;
-    WfBuffers Bj;
-    Bj.ctrl = B.ctrl + 64 * j;
-    Bj.planes = B.planes + (size_t)2 * WF_TYPES * WF_PLANES * ((size_t)t0 * 64u);
-    Bj.capacity = Q.tileCount * 64u;
+    Q[j] = P;
+    Q[j].tileFirst = t0;
+    Q[j].tileCount = t1 - t0;
+    Bj[j].ctrl = B.ctrl + 64 * j;
+    Bj[j].planes = B.planes + (size_t)2 * WF_TYPES * WF_PLANES * ((size_t)t0 * 64u);
+    Bj[j].capacity = Q[j].tileCount * 64u;
     if((e = hipStreamWaitEvent(async->streams[j], async->fork, 0)) != hipSuccess) return e;
-    if((e = launchSubframe(Q, Bj, travBlock, count, async->streams[j], nullptr)) != hipSuccess) return e;
+    if((e = subframeBegin(Q[j], Bj[j], async->streams[j])) != hipSuccess) return e;
+  }
+  // The rounds are enqueued INTERLEAVED -- round r of every sub-frame before round r + 1 of any: enqueueing one sub-frame's ~290
+  // launches after the other's makes stream j start j x ~1.2 ms of host time late, which a 33-ms shard of a 4K frame feels
+  // (N = 8 rehearsal 0.891 -> 0.905, profiles/r03_experiments.md #106) and a whole 1080p frame does not.
+  for(int r = 0; r < rounds; r++)
+    for(int j = 0; j < n; j++) subframeRound(Q[j], Bj[j], r, travBlock, count, async->streams[j], nullptr);
+  for(int j = 0; j < n; j++)
+  {
     if((e = hipEventRecord(async->join[j], async->streams[j])) != hipSuccess) return e;
     if((e = hipStreamWaitEvent(stream, async->join[j], 0)) != hipSuccess) return e;
-  }
-  return hipSuccess;
-}
-
-static hipError_t launchSubframe(const TraceParams& P, const WfBuffers& B, unsigned travBlock, bool count, hipStream_t stream, WfTiming* timing)
-{
-  const unsigned work = P.tileCount * 64u;
-  hipError_t e = hipMemsetAsync(B.ctrl, 0, 64, stream);
-  if(e != hipSuccess)
-    return e;
-  const unsigned blocks = (work + WF_BLOCK - 1) / WF_BLOCK;
-  hipLaunchKernelGGL(k_wf_init, dim3(blocks), dim3(WF_BLOCK), 0, stream, P, B);
-  if(P.pc.samples <= 0 || P.pc.depth <= 0)
-    return hipGetLastError();
-  const dim3 bb(WF_BLOCK);
-  // a sample takes at most depth + 1 rounds: its first closest-hit ray, then one round per further segment (the shadow ray of
-  // segment k travels with the closest-hit ray of segment k + 1), then the shadow ray of its last segment
-  const int rounds = P.pc.samples * (P.pc.depth + 1);
-  if(timing)
-    timing->used = 0;
-  // every path holds one record and a record at most two rays; +4 blocks for the partial tails of the four ray kinds.
-  // One wavefront per workgroup by default: a finished wave frees its slot and LDS without waiting for three others.
-  const dim3 tg(2 * ((work + travBlock - 1) / travBlock) + 4);
-  const size_t tlds = (size_t)P.sc.stackCap * travBlock * sizeof(int);
-  for(int r = 0; r < rounds; r++)
-  {
-    const bool timed = timing && timing->events && 2 * (timing->used + 1) <= timing->capacity;
-    if(timed)
-      (void)hipEventRecord(timing->events[2 * timing->used], stream);
-    launchTraverse(P, B, r, travBlock, count, tg, tlds, stream);
-    if(timed)
-    {
-      (void)hipEventRecord(timing->events[2 * timing->used + 1], stream);
-      timing->used++;
-    }
-    hipLaunchKernelGGL(k_wf_shade, dim3(blocks + 3), bb, 0, stream, P, B, r);
   }
   return hipGetLastError();
 }
