@@ -14,6 +14,7 @@
  *   createTopLevelAsGltf()     :1031                vkrt_accel_build (same call)
  *   updateUniformBuffer()      :61                  GlobalUniforms* argument
  *   pathtrace()                :1423                vkrt_pathtrace
+ *   the frame loop at rest     main.cpp:503-508     vkrt_pathtrace_frames (n progressive frames per call)
  *   resetFrame()/updateFrame() :1501-1521           caller-owned PushConstantRay.frame
  *   destroyResources()         :518                 vkrt_scene_destroy
  *
@@ -37,7 +38,10 @@
 extern "C" {
 #endif
 
-#define VKRT_ABI_VERSION 2 /* 2: vkrt_scene_set_option / vkrt_reserve, vkrt_counters.traversal_faults; options 10, 11 added in place (round 3) */
+#define VKRT_ABI_VERSION 3 /* 2: vkrt_scene_set_option / vkrt_reserve, vkrt_counters.traversal_faults.
+                              3: vkrt_pathtrace_frames, VKRT_TRACE_SAME_SEED_EVERY_FRAME, options 10-14, vkrt_accel_info.reference_count,
+                                 vkrt_accel_check.triangles_uncovered, VKRT_INFO_ANYHIT_ORDER (the options and the query
+                                 that round 3 had added under version 2 are part of 3: a client that needs them asks for >= 3) */
 
 enum vkrt_status {
   VKRT_OK = 0,
@@ -138,7 +142,9 @@ enum vkrt_trace_flags {
    * wavefront pipeline, the hit / diffuse-lobe / texture-tap tallies of the shading stage.  Rays and pixels are always counted. */
   VKRT_TRACE_COUNT_TRAVERSAL = 0x2,
   /* Record HIP events around every traversal-kernel launch of the frame (vkrt_last_trace_timing). */
-  VKRT_TRACE_TIME_KERNELS = 0x4
+  VKRT_TRACE_TIME_KERNELS = 0x4,
+  /* vkrt_pathtrace_frames: every frame of the call uses opts->seed instead of opts->seed + i (a host that does not advance its seed) */
+  VKRT_TRACE_SAME_SEED_EVERY_FRAME = 0x8
 };
 
 typedef struct vkrt_trace_opts {
@@ -172,6 +178,8 @@ typedef struct vkrt_accel_info {
   float    build_ms;         /* wall time of the last build */
   uint64_t node_bytes;
   uint64_t triangle_bytes;
+  uint32_t reference_count;  /* triangle slots of the tree = leaves' references; > triangle_count when VKRT_OPT_SPLIT_BUDGET split triangles */
+  uint32_t reserved;
 } vkrt_accel_info;
 
 /* ---- library ---------------------------------------------------------------------- */
@@ -226,7 +234,18 @@ enum vkrt_option {
                                    decision here is a pure function of the ray and the triangle: rnd(tea(triangle id, prd.seed when the ray is traced)) >
                                    dissolve; prd.seed itself is not advanced.  The result stays a property of the triangle set (any tree, any schedule);
                                    the oracle implements the same rule (orc_set_dissolve).  env VKRT_ANYHIT_DISSOLVE */
-  VKRT_OPT_LAST            = 12,
+  VKRT_OPT_WF_FRAMES_IN_FLIGHT = 13, /* vkrt_pathtrace_frames: consecutive frames of a call rendered at the same time, 1..8 (default 3), each on
+                                   record streams of its own (864 B per pixel and frame in flight); their pixel values meet in the ordered blend at
+                                   the end of a frame, so the image is bit-identical for every value.  A call with frames in flight does not split
+                                   its frames into sub-frames (option 3): few, large launches overlap best.  env VKRT_WF_FRAMES_IN_FLIGHT */
+  VKRT_OPT_SPLIT_BUDGET    = 14, /* [build] NOT a pixel-changing knob: triangle pre-splitting in the device builders (VKRT_BUILD_PLOC_GPU /
+                                   VKRT_BUILD_LBVH_GPU), the part of PREFER_FAST_TRACE (hello_vulkan.cpp:1010, :1046) that matters on artist-made
+                                   geometry.  Value = budget of EXTRA triangle references in percent of the triangle count, 0..100 (0 = off): triangles
+                                   that are large against the scene grid enter the tree as several references, each with the box of one piece of
+                                   the triangle.  Only references multiply (a copy of the 48-byte record per reference): the hit test, the triangle id
+                                   of the tie rule and every pixel are unchanged.  vkrt_accel_info.reference_count reports the result.
+                                   env VKRT_SPLIT_BUDGET */
+  VKRT_OPT_LAST            = 14,
   VKRT_INFO_ANYHIT_ORDER   = 100 /* read-only (vkrt_scene_get_option; set is refused): the child-order bits (2 | 4) that the last vkrt_accel_build
                                    resolved VKRT_OPT_WF_SHARE_FLAGS to, i.e. what bit 3 ("automatic") decided for this scene; 0 before a build */
 };
@@ -256,6 +275,19 @@ int vkrt_reserve(vkrt_scene* scene, const vkrt_shard* shard, void* hip_stream);
 int vkrt_pathtrace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam,
                    const vkrt_trace_opts* opts, const vkrt_shard* shard,
                    float* rgba32f_device, void* hip_stream);
+
+/* n_frames progressive frames of an unchanged camera in one call: the reference's render loop with the camera at rest
+ * (main.cpp:503-508: updateFrame() -> pathtrace(), frame after frame; hello_vulkan.cpp:1501-1521 advances pcRay.frame, raytrace.rgen:136-145
+ * blends frame f into the image with weight 1 / (f + 1)).  Frame i of the call (0 <= i < n_frames) is traced with pc->frame + i and
+ * opts->seed + i (opts->seed with VKRT_TRACE_SAME_SEED_EVERY_FRAME); the image afterwards is bit for bit what n_frames vkrt_pathtrace calls
+ * with those values would have left.  Inside the call consecutive frames run at the same time (VKRT_OPT_WF_FRAMES_IN_FLIGHT): the
+ * launches of one frame fill the tails of the other's, which a sequence of single-frame calls -- each complete before the next
+ * begins -- cannot do.  Same asynchrony, ordering and
+ * shard rules as vkrt_pathtrace (which is this call with n_frames = 1); vkrt_counters and vkrt_last_trace_ms cover the whole call.
+ * Working set: vkrt_reserve sizes it for the frames the current options keep in flight. */
+int vkrt_pathtrace_frames(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam,
+                          const vkrt_trace_opts* opts, const vkrt_shard* shard,
+                          float* rgba32f_device, uint32_t n_frames, void* hip_stream);
 
 /* ---- hybrid mode (reference rtMode == 0; SURVEY.md 8f row 1, BASELINE config 5) --------------------- */
 /* The four raster planes that raytraceHybrid.rgen reads (RtxBindings 1,3,4,6; host_device.h:51-63,
@@ -331,17 +363,22 @@ int vkrt_last_trace_timing(vkrt_scene* scene, vkrt_trace_timing* out);
 
 /* ---- test hooks (used by tests/ to compare single pieces with the oracle) ---------- */
 /* Structural check of the built acceleration structure (downloads it; host walk).  A tree is sound when every triangle slot
- * is referenced by exactly one leaf, every node is reached exactly once from the root, and every triangle lies inside the
- * decoded box of each of its ancestors' child slots (the quantised boxes are conservative).  Any builder, both layouts. */
+ * is referenced by exactly one leaf, every node is reached exactly once from the root, every instanced triangle owns at least one
+ * slot, and every triangle is covered by the boxes above its slots: with one slot, its three vertices lie inside the decoded box
+ * of each of that slot's ancestors (the quantised boxes are conservative); with several (VKRT_OPT_SPLIT_BUDGET), every point of a
+ * 45-point barycentric lattice on the triangle (vertices, edges, interior) lies inside ALL ancestor boxes of at least one of its
+ * slots -- the slots together must leave no part of the triangle unreachable.  Any builder, both layouts. */
 typedef struct vkrt_accel_check {
   uint64_t nodes_reached;        /* == vkrt_accel_info.node_count */
   uint64_t triangles_referenced; /* leaf references in total */
   uint64_t triangles_missing;    /* slots no leaf references */
   uint64_t triangles_repeated;   /* references beyond the first of a slot */
-  uint64_t box_violations;       /* (triangle, ancestor slot) pairs with a vertex outside the slot's box */
+  uint64_t box_violations;       /* single-slot triangles: (triangle, ancestor slot) pairs with a vertex outside the slot's box */
   uint64_t bad_references;       /* child / triangle indices out of range, nodes reached twice */
   uint32_t max_depth;            /* nodes on the longest root-to-leaf path */
   uint32_t layout;               /* 1 = 8-wide compressed, 0 = BVH2 */
+  uint64_t triangles_uncovered;  /* multi-slot triangles with a lattice point that no slot's chain of boxes contains; triangles without any slot */
+  uint64_t triangles_split;      /* triangles that own more than one slot */
 } vkrt_accel_check;
 int vkrt_debug_check_accel(vkrt_scene* scene, vkrt_accel_check* out);
 /* Closest-hit query for n rays: o,d = vec3[n] host arrays; tmin/tmax scalars.

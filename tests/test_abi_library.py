@@ -60,12 +60,14 @@ def test_argument_validation_and_no_cpu_fallback(cornell_flat):
         desc, keep = bad.to_desc()
         assert lib.vkrt_scene_create(C.byref(desc), 0, C.byref(h)) == 1
         assert b"not finite" in lib.vkrt_last_error() and not h.value
-    # options 10-12 exist (watertight test, dead-shadow-ray skipping, any-hit dissolve stage); 13 does not
+    # options 10-12 (watertight test, dead-shadow-ray skipping, any-hit dissolve stage) and 13-14 (frames in flight, triangle
+    # pre-splitting) exist; 15 does not.  ABI version 3 is the first that promises them (and vkrt_pathtrace_frames)
     from vkrt_amd import abi
 
     assert (abi.VKRT_OPT_WATERTIGHT, abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, abi.VKRT_OPT_ANYHIT_DISSOLVE) == (10, 11, 12)
     hdr = open(os.path.join(ROOT, "include", "vkrt.h")).read()
-    assert "VKRT_OPT_LAST            = 12" in hdr
+    assert (abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT, abi.VKRT_OPT_SPLIT_BUDGET) == (13, 14)
+    assert "VKRT_OPT_LAST            = 14" in hdr and "#define VKRT_ABI_VERSION 3" in hdr and abi.VKRT_ABI_VERSION == 3
     desc, keep = cornell_flat.to_desc()
     if lib.vkrt_device_count() == 0:
         # the product never computes on the CPU: without a device creation must fail loudly
@@ -93,7 +95,7 @@ def test_shard_rows_math():
 def test_ctypes_mirror_matches_header_struct_sizes(tmp_path):
     """abi.py restates include/vkrt.h by hand: compile the header and compare sizeof of every struct the harness passes."""
     pairs = {"vkrt_prim_mesh": abi.PrimMesh, "vkrt_node": abi.Node, "vkrt_texture": abi.Texture, "vkrt_scene_desc": abi.SceneDesc,
-             "vkrt_shard": abi.Shard, "vkrt_trace_opts": abi.TraceOpts, "vkrt_counters": abi.Counters, "vkrt_accel_info": abi.AccelInfo,
+             "vkrt_shard": abi.Shard, "vkrt_trace_opts": abi.TraceOpts, "vkrt_counters": abi.Counters, "vkrt_accel_info": abi.AccelInfo, "vkrt_accel_check": abi.AccelCheck,
              "vkrt_gbuffer": abi.Gbuffer, "vkrt_trace_timing": abi.TraceTiming, "GlobalUniforms": abi.GlobalUniforms,
              "PushConstantRay": abi.PushConstantRay, "PushConstantPost": abi.PushConstantPost, "GltfPBRMaterial": abi.GltfPBRMaterial,
              "GltfLight": abi.GltfLight, "PrimMeshInfo": abi.PrimMeshInfo}

@@ -1,0 +1,172 @@
+"""vkrt_pathtrace_frames: n progressive frames of an unchanged camera in ONE call (the reference's frame loop at rest,
+main.cpp:503-508 + hello_vulkan.cpp:1501-1521 + raytrace.rgen:136-145) must leave exactly the image that n vkrt_pathtrace
+calls leave -- whatever the library keeps in flight inside the call (frames in flight with the ordered blend, tile ranges
+chained without joins) -- and that image must be the oracle's."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import default_camera
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+THREADS = min(16, os.cpu_count() or 1)
+
+
+def sha(img):
+    return hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def atrium_mid():
+    import atrium
+
+    flat, info = atrium.build_atrium(60000, seed=5, with_textures=True)
+    return flat, atrium.DEFAULT_CAMERA
+
+
+def _options():
+    from vkrt_amd import abi
+
+    F, S = abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT, abi.VKRT_OPT_WF_SUBFRAMES
+    return [{}, {F: 1, S: 1}, {F: 1, S: 3}, {F: 1, S: 4}, {F: 2, S: 1}, {F: 2, S: 3}, {F: 3}, {F: 4, S: 2}, {F: 8}]
+
+
+def test_frames_call_equals_single_frame_calls_whatever_is_in_flight(atrium_mid):
+    """k = 1..5 frames in one call == k single calls, first frame 0 and first frame 3 (blend into a kept image), for every
+    lane configuration; counters agree too (same rays)."""
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat, camkw = atrium_mid
+    W, H = 640, 360  # 3600 tiles: enough for four tile ranges
+    cam = default_camera(W, H, **camkw)
+    lights = len(flat.lights)
+    ref = Renderer(flat, device=0, build="ploc")
+    want, rays = {}, {}
+    for first in (0, 3):
+        img = None
+        if first:
+            for f in range(first):
+                img = ref.pathtrace(make_push_constants(samples=2, depth=5, frame=f, lights_count=lights), cam, W, H, seed=70 + f, image=img)
+        ref.reset_counters()
+        for k in range(1, 6):
+            f = first + k - 1
+            img = ref.pathtrace(make_push_constants(samples=2, depth=5, frame=f, lights_count=lights), cam, W, H, seed=70 + f, image=img)
+            want[(first, k)] = sha(img)
+            c = ref.counters()
+            rays[(first, k)] = (c["rays_closest"], c["rays_shadow"], c["pixels"])
+    # the image after frames 0..2, the starting point of the `first = 3` calls
+    start3 = None
+    for f in range(3):
+        start3 = ref.pathtrace(make_push_constants(samples=2, depth=5, frame=f, lights_count=lights), cam, W, H, seed=70 + f, image=start3)
+    start3 = start3.clone()
+    ref.close()
+    for first in (0, 3):  # every frame changes the image
+        assert len({want[(first, k)] for k in range(1, 6)}) == 5
+    for opts in _options():
+        r = Renderer(flat, device=0, build="ploc", options=opts)
+        for first in (0, 3):
+            for k in (1, 2, 3, 5):
+                img = start3.clone() if first else None
+                r.reset_counters()
+                img = r.pathtrace_frames(make_push_constants(samples=2, depth=5, frame=first, lights_count=lights), cam, W, H, k, seed=70 + first, image=img)
+                assert sha(img) == want[(first, k)], (opts, first, k)
+                c = r.counters()
+                assert (c["rays_closest"], c["rays_shadow"], c["pixels"]) == rays[(first, k)], (opts, first, k)
+                assert c["traversal_faults"] == 0
+        r.close()
+
+
+def test_frames_call_sharded_and_same_seed_flag(atrium_mid):
+    """A shard of three renders its strips through the frames call like the whole image does; VKRT_TRACE_SAME_SEED_EVERY_FRAME
+    keeps opts->seed for every frame of the call (a host that does not advance its seed)."""
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+    from vkrt_amd.sharding import make_shard, shard_row_indices
+
+    flat, camkw = atrium_mid
+    W, H = 512, 300
+    cam = default_camera(W, H, **camkw)
+    lights = len(flat.lights)
+    r = Renderer(flat, device=0, build="ploc", options={abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT: 2, abi.VKRT_OPT_WF_SUBFRAMES: 2})
+    for same_seed in (False, True):
+        whole = None
+        for f in range(4):
+            whole = r.pathtrace(make_push_constants(samples=1, depth=4, frame=f, lights_count=lights), cam, W, H, seed=9 + (0 if same_seed else f), image=whole)
+        whole = whole.cpu().numpy()
+        flags = abi.VKRT_TRACE_SAME_SEED_EVERY_FRAME if same_seed else 0
+        full = r.pathtrace_frames(make_push_constants(samples=1, depth=4, frame=0, lights_count=lights), cam, W, H, 4, seed=9, flags=flags)
+        assert np.array_equal(full.cpu().numpy().view(np.uint32), whole.view(np.uint32))
+        for rank in range(3):
+            shard = make_shard(W, H, 3, rank)
+            part = r.pathtrace_frames(make_push_constants(samples=1, depth=4, frame=0, lights_count=lights), cam, W, H, 4, seed=9, flags=flags, shard=shard)
+            assert np.array_equal(part.cpu().numpy().view(np.uint32), whole[shard_row_indices(H, 3, rank)].view(np.uint32)), (same_seed, rank)
+    # an empty call and a shard without rows are no-ops
+    assert r.lib.vkrt_pathtrace_frames(r._h, None, None, None, None, None, 0, None) == 1  # NULL arguments are still refused
+    none = make_shard(W, 16, 4, 3)  # one strip, four shards: shard 3 has no rows
+    assert r.shard_rows(none) == 0
+    r.close()
+
+
+def test_frames_call_megakernel_mode_and_degenerate_launch(cornell_flat):
+    """The megakernel mode renders the frames of a call one after another; a launch without rays (depth 0) stores black."""
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    W, H = 200, 160
+    cam = default_camera(W, H)
+    r0 = Renderer(cornell_flat, device=0, build="sah")
+    want = None
+    for f in range(3):
+        want = r0.pathtrace(make_push_constants(samples=3, depth=3, frame=f, lights_count=1), cam, W, H, seed=5 + f, image=want)
+    r0.close()
+    for opts in ({abi.VKRT_OPT_MODE: 0}, {abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT: 2}, {abi.VKRT_OPT_BVH_LAYOUT: 0, abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT: 3}):
+        r = Renderer(cornell_flat, device=0, build="sah", options=opts)
+        got = r.pathtrace_frames(make_push_constants(samples=3, depth=3, frame=0, lights_count=1), cam, W, H, 3, seed=5)
+        assert sha(got) == sha(want), opts
+        z = r.pathtrace_frames(make_push_constants(samples=3, depth=0, frame=0, lights_count=1), cam, W, H, 2, seed=5)
+        assert float(z[..., :3].abs().max()) == 0.0
+        r.close()
+
+
+@pytest.mark.parametrize("rank", [5])
+def test_config4_shard_through_the_frames_call_rows_match_oracle(rank):
+    """BASELINE config 4, one rank's share (3840x2160, 16 spp, depth 8, shard 5 of 8): TWO progressive frames in one call with two
+    frames in flight, against oracle rows rendered frame by frame."""
+    import atrium
+    import oracle_py
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+    from vkrt_amd.sharding import make_shard, shard_row_indices
+
+    flat, info = atrium.build_atrium(262144, seed=1, with_textures=True)
+    W, H = 3840, 2160
+    cam = default_camera(W, H, **atrium.DEFAULT_CAMERA)
+    lights = len(flat.lights)
+    shard = make_shard(W, H, 8, rank)
+    grow = shard_row_indices(H, 8, rank)
+    r = Renderer(flat, device=0, build="ploc", options={abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT: 2})
+    r.reserve(shard)
+    part = r.pathtrace_frames(make_push_constants(samples=16, depth=8, frame=0, lights_count=lights), cam, W, H, 2, seed=0, shard=shard).cpu().numpy()
+    c = r.counters()
+    r.close()
+    assert c["traversal_faults"] == 0 and c["pixels"] == 2 * len(grow) * W
+    pick = np.unique(np.linspace(0, len(grow) - 1, 5).astype(np.int64))
+    orc = oracle_py.OracleScene(flat)
+    ref = None
+    for f in range(2):
+        ref, _ = orc.render(make_push_constants(samples=16, depth=8, frame=f, lights_count=lights), cam, W, H, seed=f, rows=grow[pick].astype(np.uint32),
+                            image=ref, threads=THREADS)
+    got = part[pick]
+    rmse = float(np.sqrt(np.mean((got[..., :3].astype(np.float64) - ref[..., :3].astype(np.float64)) ** 2)))
+    assert rmse < 1e-3
+    assert float(np.mean(np.any(got.view(np.uint32) != ref.view(np.uint32), axis=-1))) < 1e-4

@@ -149,6 +149,7 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
     """force_opts: {option: value} applied on top of the case's own draw (e.g. the watertight test for a recorded seed)."""
     rng = np.random.default_rng(seed)
     rng3 = np.random.default_rng([seed, 3])  # round-3 options come from their own stream: the cases of earlier campaigns keep their draws
+    rng4 = np.random.default_rng([seed, 4])  # round 4: triangle pre-splitting, frames in one call
     flat = random_scene(rng)
     W, H = int(rng.integers(8, 64)), int(rng.integers(8, 48))
     if rng.random() < 0.08:  # now and then an image large enough for the sub-frame pipeline (>= 512 tiles)
@@ -181,8 +182,14 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
         for m in flat.materials:
             if rng3.random() < 0.6:
                 m["pbrBaseColorFactor"][3] = float(rng3.choice([0.0, 0.05, 0.5, 0.95, float(rng3.random())]))
+    if rng4.random() < 0.35: opts[abi.VKRT_OPT_SPLIT_BUDGET] = int(rng4.choice([10, 30, 100]))  # several references per large triangle (device builders)
+    frames_call = rng4.random() < 0.3  # the frames of the sequence in ONE vkrt_pathtrace_frames call, with whatever lanes the draw gives
+    if frames_call:
+        opts[abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT] = int(rng4.integers(1, 5))
     opts.update(force_opts or {})
     spp, depth, frames = int(rng.integers(1, 4)), int(rng.integers(1, 7)), int(rng.integers(1, 3))
+    if frames_call and rng4.random() < 0.5:
+        frames = int(rng4.integers(2, 6))
     L = int(rng.integers(1, len(flat.lights) + 1))
     if rng.random() < 0.05:  # long sample sequences and deep paths (pixels far out of step with each other in the paired rounds)
         spp, depth = int(rng.integers(4, 12)), int(rng.integers(7, 16))
@@ -202,9 +209,13 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
     brute = bool(rng.random() < 0.3) and W * H * spp * frames < 6000  # the oracle's loop over all triangles as the referee
     try:
         img = ref = None
+        if frames_call:  # (a call that starts at frame > 0 blends into the zero image, like the single-frame calls below do)
+            img = r.pathtrace_frames(make_push_constants(samples=spp, depth=depth, frame=first_frame, lights_count=L), cam, W, H, frames,
+                                     seed=seed + first_frame, flags=flags, image=img)
         for f in range(first_frame, first_frame + frames):
             pc = make_push_constants(samples=spp, depth=depth, frame=f, lights_count=L)
-            img = r.pathtrace(pc, cam, W, H, seed=seed + f, flags=flags, image=img)
+            if not frames_call:
+                img = r.pathtrace(pc, cam, W, H, seed=seed + f, flags=flags, image=img)
             ref, _ = orc.render(pc, cam, W, H, seed=seed + f, flags=flags, image=ref, use_bvh=not brute)
         got = img.cpu().numpy()
         same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
@@ -235,7 +246,7 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
         if c["traversal_faults"]:
             problems.append(("faults", c["traversal_faults"], 0))
         chk = r.check_accel()
-        if chk["triangles_missing"] or chk["triangles_repeated"] or chk["box_violations"] or chk["bad_references"]:
+        if chk["triangles_missing"] or chk["triangles_repeated"] or chk["box_violations"] or chk["bad_references"] or chk["triangles_uncovered"]:
             problems.append(("tree", chk, 0))
         if rng.random() < 0.35 and abi.VKRT_OPT_MODE not in opts:  # a random image-strip shard equals the rows of the whole frame
             count = int(rng.integers(2, 6)); index = int(rng.integers(0, count)); strip = int(rng.choice([1, 3, 16]))

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Device assembly of wavefront.hip for one build variant (EXP number or empty) and the register / instruction statistics of k_wf_traverse:
-#   tools/isa_stats.sh [EXP] -> /tmp/vkrt_isa/wavefront[_expN].s
+# Device assembly of wavefront.hip (optionally with extra -D flags) and the register / instruction statistics of its kernels:
+#   tools/isa_stats.sh [name "-DFOO=1"] -> /tmp/vkrt_isa/wavefront[_name].s
 set -e
-EXP=$1; OUT=/tmp/vkrt_isa; mkdir -p $OUT
-S=$OUT/wavefront${EXP:+_exp$EXP}.s
+NAME=$1; DEFS=$2; OUT=/tmp/vkrt_isa; mkdir -p $OUT
+S=$OUT/wavefront${NAME:+_$NAME}.s
 cd "$(dirname "$0")/../vk-raytracing-engine_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sched-strategy=max-memory-clause \
-  ${EXP:+-DVKRT_EXP=$EXP} --cuda-device-only -S -o $S wavefront.hip 2>/dev/null
+  $DEFS --cuda-device-only -S -o $S wavefront.hip 2>/dev/null
 for k in _Z13k_wf_traverseILb0ELb1ELi64ELi0EEv11TraceParams9WfBuffersi _Z13k_wf_traverseILb1ELb1ELi64ELi0EEv11TraceParams9WfBuffersi; do
   awk -v k="$k" '$0 ~ "^"k":" {on=1} on {print} on && /s_endpgm/ {exit}' $S > $OUT/body.s
   echo "$k: instr $(grep -c -E '^\s+(v_|s_|global_|ds_|buffer_|scratch_)' $OUT/body.s) valu $(grep -c -E '^\s+v_' $OUT/body.s) fma_mix $(grep -c v_fma_mix $OUT/body.s) cvt_ubyte $(grep -c v_cvt_f32_ubyte $OUT/body.s) cndmask $(grep -c v_cndmask $OUT/body.s) loadx4 $(grep -c global_load_dwordx4 $OUT/body.s)"

@@ -109,7 +109,7 @@ class Shard(C.Structure):
 class AccelCheck(C.Structure):
     _fields_ = [("nodes_reached", C.c_uint64), ("triangles_referenced", C.c_uint64), ("triangles_missing", C.c_uint64),
                 ("triangles_repeated", C.c_uint64), ("box_violations", C.c_uint64), ("bad_references", C.c_uint64),
-                ("max_depth", c_u), ("layout", c_u)]
+                ("max_depth", c_u), ("layout", c_u), ("triangles_uncovered", C.c_uint64), ("triangles_split", C.c_uint64)]
 
 
 class TraceOpts(C.Structure):
@@ -145,6 +145,8 @@ class AccelInfo(C.Structure):
         ("build_ms", c_f),
         ("node_bytes", c_u64),
         ("triangle_bytes", c_u64),
+        ("reference_count", c_u),
+        ("reserved", c_u),
     ]
 
 
@@ -180,12 +182,14 @@ VKRT_BUILD_PLOC_GPU = 0x4
 VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1
 VKRT_TRACE_COUNT_TRAVERSAL = 0x2
 VKRT_TRACE_TIME_KERNELS = 0x4
-VKRT_ABI_VERSION = 2
+VKRT_TRACE_SAME_SEED_EVERY_FRAME = 0x8
+VKRT_ABI_VERSION = 3
 # vkrt_option
 VKRT_OPT_MODE, VKRT_OPT_BVH_LAYOUT, VKRT_OPT_WF_SUBFRAMES, VKRT_OPT_WF_TRAV_BLOCK = 1, 2, 3, 4
 VKRT_OPT_WF_SHARE, VKRT_OPT_TRI_THRESHOLD, VKRT_OPT_WF_SHARE_PERIOD, VKRT_OPT_WF_SHARE_FLAGS = 5, 6, 7, 8
 VKRT_OPT_GBUFFER_MIPS = 9
 VKRT_OPT_WATERTIGHT, VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, VKRT_OPT_ANYHIT_DISSOLVE = 10, 11, 12
+VKRT_OPT_WF_FRAMES_IN_FLIGHT, VKRT_OPT_SPLIT_BUDGET = 13, 14
 VKRT_INFO_ANYHIT_ORDER = 100  # read-only: what the build resolved the any-hit child order to
 
 # every symbol include/vkrt.h declares (tests check the built library exports them all)
@@ -202,6 +206,7 @@ VKRT_SYMBOLS = [
     "vkrt_accel_get_info",
     "vkrt_shard_rows",
     "vkrt_pathtrace",
+    "vkrt_pathtrace_frames",
     "vkrt_gbuffer_raycast",
     "vkrt_hybrid_trace",
     "vkrt_gbuffer_raycast_nrd",
@@ -245,6 +250,10 @@ def declare_vkrt(lib):
         C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), C.c_void_p, C.c_void_p,
     ]
     lib.vkrt_pathtrace.restype = C.c_int
+    lib.vkrt_pathtrace_frames.argtypes = [
+        C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), C.c_void_p, c_u, C.c_void_p,
+    ]
+    lib.vkrt_pathtrace_frames.restype = C.c_int
     lib.vkrt_gbuffer_raycast.argtypes = [C.c_void_p, P(c_f * 4), C.c_int, P(GlobalUniforms), P(Shard), P(Gbuffer), C.c_void_p]
     lib.vkrt_gbuffer_raycast.restype = C.c_int
     lib.vkrt_hybrid_trace.argtypes = [C.c_void_p, P(PushConstantRay), P(GlobalUniforms), P(TraceOpts), P(Shard), P(Gbuffer), C.c_void_p, C.c_void_p]

@@ -332,15 +332,7 @@ namespace vkrt {
 namespace {
 
 constexpr float kNodeCost = 1.0f;
-#if defined(VKRT_EXP) && VKRT_EXP == 12
-constexpr float kPrimCost = 0.6f;  // experiment #101: relative cost of a triangle test in the collapse's cost model
-#elif defined(VKRT_EXP) && VKRT_EXP == 13
-constexpr float kPrimCost = 1.5f;
-#elif defined(VKRT_EXP) && VKRT_EXP == 14
-constexpr float kPrimCost = 0.3f;
-#else
-constexpr float kPrimCost = 1.0f;
-#endif
+constexpr float kPrimCost = 1.0f;  // (0.3 / 0.6 / 1.5 measured and rejected, profiles/r03_experiments.md #101)
 
 struct W8Child
 {

@@ -113,8 +113,9 @@ struct DevCounters
 };
 
 // TraceParams.flags: the public vkrt_trace_flags (include/vkrt.h) in the low bits + internal launch-uniform switches
-#define VKRT_TRACE_PUBLIC_FLAGS 0x7u
+#define VKRT_TRACE_PUBLIC_FLAGS 0xFu
 #define VKRT_FLAG_SKIP_DEAD_SHADOW 0x100u  // VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: a diffuse hit whose contribution is exactly zero emits no shadow ray
+#define VKRT_FLAG_STORE_STAGED 0x200u      // frames in flight: `image` is the frame's staging plane; storePixel writes the pixel value unblended
 
 struct TraceParams
 {
@@ -134,10 +135,13 @@ struct TraceParams
   DevCounters* counters;
 };
 
-// Wavefront-mode working set (wavefront.hip): four record streams [parity][type] of SoA float4 planes + their counts.
+// Wavefront-mode working set (wavefront.hip): six record streams [parity][type] of SoA float4 planes + their counts, once per
+// frame group (frames in flight), and the staging plane of each group.
 struct WfBuffers
 {
-  unsigned* ctrl;       // stream counts [parity*2 + type], type 0 = closest-hit rays, 1 = shadow rays
-  float4* planes;       // [parity*2 + type][plane][capacity]
+  unsigned* ctrl;       // stream counts [parity * 4 + type]; 64 words per lane
+  float4* planes;       // [group][parity * 3 + type][plane][capacity]
+  float4* stage;        // [group][capacity]: pixel values of a frame in flight, shard-local image layout (groups > 1 only)
   uint32_t capacity;    // paths (pixels of the shard, rounded up to whole 8x8 tiles)
+  uint32_t groups;      // frame groups the allocation holds
 };

@@ -96,7 +96,9 @@ VKRT_DEV bool pixelOf(const TraceParams& P, uint32_t& x, uint32_t& y, uint32_t& 
   return y < P.fullH;
 }
 
-template <bool WIDE, bool WT>
+// TM: VKRT_TM_WATERTIGHT and / or VKRT_TM_MASKID (a raster pass has no any-hit stage -- every triangle is opaque here -- but on a scene
+// built for the stage the id words carry its flag, which the tie rule "smallest triangle id" and the exclusive tmax must not see)
+template <bool WIDE, int TM>
 __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
 {
   extern __shared__ int lds_stack[];
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
     const f3 org = mk3(origin[0], origin[1], origin[2]), dir = primaryDir(P, x, y);
     RayHit hit;
     nClosest = 1;
-    traverse_any<false, WIDE, WT ? VKRT_TM_WATERTIGHT : 0>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);  // (a raster pass has no any-hit stage: opaque)
+    traverse_any<false, WIDE, TM>(sc, org, dir, 0.001f, 10000.0f, false, lds_stack, (int)threadIdx.x, HY_BLOCK, hit, tc);
     if(hit.slot >= 0)
     {
       const float4 recq = sc.tris[hit.slot * VKRT_TRI_QUADS + 2];
@@ -533,17 +535,29 @@ hipError_t vkrt_launch_gbuffer(const TraceParams& P, const float clearColor[4], 
   H.lightsCount = lightsCount;
   const unsigned blocks = (P.tileCount * 64u + HY_BLOCK - 1) / HY_BLOCK;
   const size_t lds = (size_t)P.sc.stackCap * HY_BLOCK * sizeof(int);
-  const bool wt = P.sc.watertight != 0u;
+  const int tm = (P.sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (P.sc.dissolve ? VKRT_TM_MASKID : 0);
+#define VKRT_GB_LAUNCH(W, TM) hipLaunchKernelGGL((k_gbuffer<W, TM>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H)
   if(P.sc.layout == 1u)
   {
-    if(wt) hipLaunchKernelGGL((k_gbuffer<true, true>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
-    else hipLaunchKernelGGL((k_gbuffer<true, false>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+    switch(tm)
+    {
+      case 0: VKRT_GB_LAUNCH(true, 0); break;
+      case VKRT_TM_WATERTIGHT: VKRT_GB_LAUNCH(true, VKRT_TM_WATERTIGHT); break;
+      case VKRT_TM_MASKID: VKRT_GB_LAUNCH(true, VKRT_TM_MASKID); break;
+      default: VKRT_GB_LAUNCH(true, VKRT_TM_WATERTIGHT | VKRT_TM_MASKID); break;
+    }
   }
   else
   {
-    if(wt) hipLaunchKernelGGL((k_gbuffer<false, true>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
-    else hipLaunchKernelGGL((k_gbuffer<false, false>), dim3(blocks), dim3(HY_BLOCK), lds, stream, H);
+    switch(tm)
+    {
+      case 0: VKRT_GB_LAUNCH(false, 0); break;
+      case VKRT_TM_WATERTIGHT: VKRT_GB_LAUNCH(false, VKRT_TM_WATERTIGHT); break;
+      case VKRT_TM_MASKID: VKRT_GB_LAUNCH(false, VKRT_TM_MASKID); break;
+      default: VKRT_GB_LAUNCH(false, VKRT_TM_WATERTIGHT | VKRT_TM_MASKID); break;
+    }
   }
+#undef VKRT_GB_LAUNCH
   return hipGetLastError();
 }
 

@@ -17,25 +17,36 @@ struct WfTiming
   int capacity;
   int used;             // pairs recorded around k_wf_traverse launches
 };
-// Sub-frames: the tiles of a frame are split into up to VKRT_WF_MAX_SUBFRAMES independent groups, each with its own
-// streams, driven from its own HIP stream so that the kernels of different groups overlap (the VALU-bound traversal of
-// one group runs beside the memory-bound shading of another, and kernel tails are filled).
-#define VKRT_WF_MAX_SUBFRAMES 8
+// Lanes.  A call renders `frames` progressive frames of one shard.  Its work is dealt to up to VKRT_WF_MAX_LANES lanes, each with its
+// own record streams and its own HIP stream, so that the kernels of different lanes overlap (a draining traversal launch of one lane
+// is filled up by the launches of the others):
+//   * a call of several frames keeps `inFlight` consecutive frames in flight, one lane each (frame k belongs to group k % inFlight).
+//     A frame in flight writes its pixel values into its group's staging plane, and a blend kernel at its end applies
+//     raytrace.rgen:136-141 in frame order (it waits for the blend of frame k - 1): the image is what single-frame calls would
+//     have left, bit for bit.  Every launch keeps its full size;
+//   * a single frame is split spatially into `subframes` tile ranges, one lane each (a pixel is always blended by its own lane).
+#define VKRT_WF_MAX_LANES 8
 struct WfAsync
 {
-  hipStream_t streams[VKRT_WF_MAX_SUBFRAMES];  // internal streams (created by the caller of vkrt_launch_wavefront)
-  hipEvent_t fork, join[VKRT_WF_MAX_SUBFRAMES];
-  int count;                                    // usable entries (0/1 = everything on the caller's stream)
+  hipStream_t streams[VKRT_WF_MAX_LANES];  // internal streams (created by the caller of vkrt_launch_wavefront)
+  hipEvent_t fork, join[VKRT_WF_MAX_LANES];
+  int count;                                // usable entries (0/1 = everything on the caller's stream)
+  hipEvent_t* pool;                         // events for the blend order of the frames of one call, no timing
+  int poolSize;
 };
-size_t     vkrt_wf_state_bytes(uint32_t pathCapacity);
-void       vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B);
+// events a call with these parameters takes from WfAsync::pool
+inline int vkrt_wf_pool_events(int frames, int lanes) { return frames * lanes; }
+size_t     vkrt_wf_state_bytes(uint32_t pathCapacity, int groups);
+void       vkrt_wf_carve(void* base, uint32_t pathCapacity, int groups, WfBuffers* B);
 struct WfOptions
 {
-  int subframes;  // VKRT_OPT_WF_SUBFRAMES
-  int travBlock;  // VKRT_OPT_WF_TRAV_BLOCK (64 / 128 / 256)
+  int subframes;   // VKRT_OPT_WF_SUBFRAMES
+  int travBlock;   // VKRT_OPT_WF_TRAV_BLOCK (64 / 128 / 256)
+  int inFlight;    // VKRT_OPT_WF_FRAMES_IN_FLIGHT (clamped to the frames of the call and to WfBuffers::groups)
 };
-hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, bool count, hipStream_t stream, WfTiming* timing,
-                                 const WfAsync* async);
+// frames >= 1: frame k uses pc.frame + k and seed + k * seedStep
+hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, int frames, uint32_t seedStep, bool count,
+                                 hipStream_t stream, WfTiming* timing, const WfAsync* async);
 
 // hybrid mode (hybrid.hip)
 struct NrdPlanes  // optional NRD front-end attachments (include/vkrt.h vkrt_nrd_planes) + the raster pass's view matrix

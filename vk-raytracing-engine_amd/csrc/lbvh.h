@@ -35,7 +35,8 @@ struct LbvhResult
   void* nodes = nullptr;  // device, 64 B per node (caller frees with hipFree)
   void* tris = nullptr;   // device, 48 B per triangle in leaf order
   void* triShade = nullptr;  // device, 16 B per triangle in leaf order (vertex indices + material)
-  uint32_t triCount = 0, nodeCount = 0, maxDepth = 0;
+  uint32_t triCount = 0, nodeCount = 0, maxDepth = 0;  // triCount = triangle SLOTS = references (leaves) of the tree
+  uint32_t uniqueTris = 0;                             // instanced triangles (== triCount without pre-splitting)
   int32_t rootRef = (int32_t)0x80000000;
   float sahCost = 0;
   std::string error;
@@ -50,8 +51,9 @@ int ploc_cluster_device(uint32_t T, const unsigned* order, const float* triBox, 
                         int* parentLeaf, float* nodeBox, unsigned* passes, std::string& err);
 
 // sc must already hold the uploaded positions / indices / instances.  ploc: cluster (ploc.hip, one triangle per leaf) instead of
-// the Morton radix tree.
+// the Morton radix tree.  splitPercent: budget of extra references for triangle pre-splitting, in percent of the triangle count (0 = off).
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4, bool wantWide = false, bool ploc = false, bool watertight = false, bool dissolve = false);
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize = 4, bool wantWide = false, bool ploc = false, bool watertight = false, bool dissolve = false,
+                      unsigned splitPercent = 0);
 
 }  // namespace vkrt

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "device_math.h"
 #include "lbvh.h"
@@ -303,13 +304,15 @@ __global__ void k_emit(unsigned kLeaf, int n, const unsigned* order, const float
 
 // materials != NULL (VKRT_OPT_ANYHIT_DISSOLVE): bit 31 of the id word of every triangle whose material has dissolve
 // (pbrBaseColorFactor.a) < 1 is set -- the flag the traversal's any-hit stage looks at (traverse.h anyhit_ignores)
+// refTri != NULL (triangle pre-splitting): order[] holds reference numbers and refTri[r] is the triangle reference r belongs to; a
+// triangle with several references gets a copy of its record (and of its shading record) in every slot
 __global__ void k_pack(unsigned n, const unsigned* order, const float4* triU, float4* outTris, FlatArgs A, const int* instMaterial,
-                       uint4* outShade, const DevMaterial* materials)
+                       uint4* outShade, const DevMaterial* materials, const unsigned* refTri)
 {
   const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
   if(s >= n)
     return;
-  const unsigned g = order[s];
+  const unsigned g = refTri ? refTri[order[s]] : order[s];
   {  // shading record: absolute vertex indices + max(0, materialIndex) (raytrace.rchit:34-50)
     const float4 c = triU[3 * (size_t)g + 2];
     const unsigned inst = (unsigned)__float_as_int(c.z), prim = (unsigned)__float_as_int(c.w);
@@ -344,6 +347,341 @@ __global__ void k_depth(unsigned kLeaf, int n, const int2* range, const int* par
     node = parentInternal[node];
   }
   atomicMax(maxDepth, d);
+}
+
+// ---- triangle pre-splitting ----------------------------------------------------------------------------------------------
+// The reference asks its driver for PREFER_FAST_TRACE (hello_vulkan.cpp:1010, :1046); what separates a trace-quality builder from a
+// plain one on artist-made geometry is what it does with triangles that are large against their neighbours: a wall of two room-sized
+// triangles, a 15-m moulding, a drapery strip hanging diagonally.  One box around such a triangle overlaps everything near it.
+// Here such triangles enter the build as SEVERAL references, each with the box of one piece of the triangle (the triangle clipped to
+// a cell of the Morton grid), after Karras & Aila 2013, "Fast Parallel Construction of High-Quality Bounding Volume Hierarchies",
+// section 4 (restated from the paper's description):
+//   priority of a triangle  p = (2^-level * (area(box) - A_ideal))^(1/3),  level = depth of the most important spatial-median plane of
+//                           the scene grid that cuts the box (0 = the plane halving the scene), A_ideal = |n.x| + |n.y| + |n.z| with
+//                           n = e1 x e2: the surface area of the boxes of infinitely small pieces;
+//   splits of a triangle    s = floor(D * p), D found by bisection so that the splits of all triangles fill the budget;
+//   one split               at the most important median plane cutting the piece's box; the remaining splits are dealt to the two
+//                           halves in proportion to the longest sides of their boxes.
+// Only references multiply: every piece points at the ORIGINAL 48-byte record (copied into each slot by k_pack), the hit test, the
+// triangle id of the tie rule and every pixel stay what they were.  A piece's box = bounds of (triangle cut by the plane), clamped
+// to the box of the piece it came from -- conservative in floating point (the cut points are padded by 8 ulp of their coordinates,
+// the needle slop of tri_prep.h is added to every piece) and never larger than the triangle's own box.
+#define VKRT_SPLIT_GRID_BITS 21          // the Morton grid of k_morton
+#define VKRT_SPLIT_MAX_PER_TRI 255u
+#define VKRT_SPLIT_STACK 16
+
+struct SplitTri
+{
+  float v[3][3];   // the vertices as the selected triangle test sees them
+  float full[6];   // the triangle's box as every builder sees it (tri_prep.h): exact bounds + slop
+  float slop;
+};
+struct SplitGrid
+{
+  float lo[3], ext[3];
+};
+
+VKRT_DEV void loadSplitTri(const float4* __restrict__ triU, const float* __restrict__ triBox, unsigned g, int watertight, SplitTri& t)
+{
+  const float4 a = triU[3 * (size_t)g], b = triU[3 * (size_t)g + 1], c = triU[3 * (size_t)g + 2];
+  const float r1[3] = {a.w, b.x, b.y}, r2[3] = {b.z, b.w, c.x};
+  t.v[0][0] = a.x; t.v[0][1] = a.y; t.v[0][2] = a.z;
+  float e1[3], e2[3];
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    t.v[1][k] = watertight ? r1[k] : t.v[0][k] + r1[k];
+    t.v[2][k] = watertight ? r2[k] : t.v[0][k] + r2[k];
+    e1[k] = watertight ? r1[k] - t.v[0][k] : r1[k];
+    e2[k] = watertight ? r2[k] - t.v[0][k] : r2[k];
+    t.full[k] = triBox[6 * (size_t)g + k];
+    t.full[3 + k] = triBox[6 * (size_t)g + 3 + k];
+  }
+  t.slop = vkrt_tri_slop(e1, e2);
+}
+
+VKRT_DEV SplitGrid loadSplitGrid(const unsigned* __restrict__ sceneBounds)
+{
+  SplitGrid G;
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    G.lo[k] = decodeOrdered(sceneBounds[k]);
+    G.ext[k] = decodeOrdered(sceneBounds[3 + k]) - G.lo[k];
+  }
+  return G;
+}
+
+VKRT_DEV unsigned splitCell(const SplitGrid& G, int k, float x)
+{
+  const float cells = (float)(1u << VKRT_SPLIT_GRID_BITS);
+  float t = G.ext[k] > 0.0f ? (x - G.lo[k]) / G.ext[k] : 0.0f;
+  t = fminf(fmaxf(t * cells, 0.0f), cells - 1.0f);
+  return (unsigned)t;
+}
+
+// The most important spatial-median plane that cuts box b: axis (or -1), its position, and the bit index m of the plane in the grid
+// (VKRT_SPLIT_GRID_BITS - 1 = the plane halving the scene).  Ties between axes go to the axis on which the box is longest.
+VKRT_DEV int splitPlane(const SplitGrid& G, const float* b, float& pos, int& mOut)
+{
+  int axis = -1, mBest = -1;
+  float extBest = 0.0f;
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    const unsigned qa = splitCell(G, k, b[k]), qb = splitCell(G, k, b[3 + k]);
+    if(qa == qb)
+      continue;
+    const int m = 31 - __clz((int)(qa ^ qb));
+    const float c = G.lo[k] + (float)((qb >> m) << m) * (G.ext[k] / (float)(1u << VKRT_SPLIT_GRID_BITS));
+    if(!(c > b[k] && c < b[3 + k]))
+      continue;  // (rounding put the plane on the box's face: nothing to cut on this axis)
+    const float ext = b[3 + k] - b[k];
+    if(m > mBest || (m == mBest && ext > extBest))
+    {
+      axis = k; mBest = m; extBest = ext; pos = c;
+    }
+  }
+  mOut = mBest;
+  return axis;
+}
+
+// Karras & Aila's priority (see above); 0 = not worth a split
+VKRT_DEV float splitPriority(const SplitGrid& G, const SplitTri& t)
+{
+  float b[6];
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    b[k] = fminf(t.v[0][k], fminf(t.v[1][k], t.v[2][k]));
+    b[3 + k] = fmaxf(t.v[0][k], fmaxf(t.v[1][k], t.v[2][k]));
+  }
+  float pos;
+  int m;
+  if(splitPlane(G, b, pos, m) < 0)
+    return 0.0f;
+  const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+  const float e1[3] = {t.v[1][0] - t.v[0][0], t.v[1][1] - t.v[0][1], t.v[1][2] - t.v[0][2]};
+  const float e2[3] = {t.v[2][0] - t.v[0][0], t.v[2][1] - t.v[0][1], t.v[2][2] - t.v[0][2]};
+  const float nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+  const float gain = 2.0f * (dx * dy + dy * dz + dz * dx) - (fabsf(nx) + fabsf(ny) + fabsf(nz));
+  if(!(gain > 0.0f))
+    return 0.0f;
+  // areas relative to the scene's: the priorities of a scene in millimetres and of the same scene in kilometres are the same
+  const float sx = G.ext[0], sy = G.ext[1], sz = G.ext[2];
+  const float sceneArea = 2.0f * (sx * sy + sy * sz + sz * sx);
+  if(!(sceneArea > 0.0f))
+    return 0.0f;
+  const float p = cbrtf(ldexpf(gain / sceneArea, m - (VKRT_SPLIT_GRID_BITS - 1)));
+  return (p == p && p < INFINITY) ? p : 0.0f;
+}
+
+// boxes of the two halves of piece `b` of triangle t cut at x_axis = pos; false when one half has no extent
+VKRT_DEV bool splitClip(const SplitTri& t, const float* b, int axis, float pos, float* L, float* R)
+{
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    L[k] = INFINITY; L[3 + k] = -INFINITY; R[k] = INFINITY; R[3 + k] = -INFINITY;
+  }
+  auto grow = [](float* d, const float* p, const float* pad) {
+#pragma unroll
+    for(int k = 0; k < 3; k++)
+    {
+      d[k] = fminf(d[k], p[k] - pad[k]);
+      d[3 + k] = fmaxf(d[3 + k], p[k] + pad[k]);
+    }
+  };
+  const float zero[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for(int e = 0; e < 3; e++)
+  {
+    const float* va = t.v[e];
+    const float* vb = t.v[(e + 1) % 3];
+    const float da = va[axis], db = vb[axis];
+    if(da <= pos) grow(L, va, zero);
+    if(da >= pos) grow(R, va, zero);
+    if((da < pos && db > pos) || (da > pos && db < pos))
+    {
+      const float w = (pos - da) / (db - da);
+      float p[3], pad[3];
+#pragma unroll
+      for(int k = 0; k < 3; k++)
+      {
+        p[k] = va[k] + w * (vb[k] - va[k]);
+        pad[k] = 4.76837158203125e-07f * fmaxf(fabsf(va[k]), fabsf(vb[k]));  // 8 * 2^-24 of the coordinates that went into p[k]
+      }
+      p[axis] = pos;
+      pad[axis] = 0.0f;
+      grow(L, p, pad);
+      grow(R, p, pad);
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    L[k] = fmaxf(L[k], b[k]); L[3 + k] = fminf(L[3 + k], b[3 + k]);
+    R[k] = fmaxf(R[k], b[k]); R[3 + k] = fminf(R[3 + k], b[3 + k]);
+  }
+  L[3 + axis] = fminf(L[3 + axis], pos);
+  R[axis] = fmaxf(R[axis], pos);
+#pragma unroll
+  for(int k = 0; k < 3; k++) ok = ok && L[k] <= L[3 + k] && R[k] <= R[3 + k];
+  return ok;
+}
+
+// The pieces of triangle g for a budget of s splits, depth first with the smaller share first (stack depth <= log2(s) + 2).
+// EMIT: writes (g, box) of every piece from slot `base` on.  Returns the number of pieces (1 .. s + 1); the same for both EMIT values.
+template <bool EMIT>
+VKRT_DEV unsigned splitTriangle(const SplitGrid& G, const SplitTri& t, unsigned s, unsigned g, unsigned base, unsigned* refTri, float* refBox)
+{
+  struct Item { float b[6]; unsigned s; };
+  Item stack[VKRT_SPLIT_STACK];
+  int sp = 1;
+#pragma unroll
+  for(int k = 0; k < 3; k++)
+  {
+    stack[0].b[k] = fminf(t.v[0][k], fminf(t.v[1][k], t.v[2][k]));
+    stack[0].b[3 + k] = fmaxf(t.v[0][k], fmaxf(t.v[1][k], t.v[2][k]));
+  }
+  stack[0].s = s;
+  unsigned n = 0;
+  while(sp > 0)
+  {
+    Item it = stack[--sp];
+    float pos = 0.0f;
+    int m;
+    int axis = -1;
+    float L[6], R[6];
+    bool cut = false;
+    while(it.s > 0u && !cut)
+    {
+      axis = splitPlane(G, it.b, pos, m);
+      if(axis < 0)
+        break;
+      if(splitClip(t, it.b, axis, pos, L, R))
+        cut = true;
+      else
+      {
+        // the triangle lies on one side of the plane inside this box: the box shrinks to that side, one split is spent
+        const bool leftOk = L[0] <= L[3] && L[1] <= L[4] && L[2] <= L[5];
+        const float* keep = leftOk ? L : R;
+        if(!(keep[0] <= keep[3] && keep[1] <= keep[4] && keep[2] <= keep[5]))
+          break;  // (cannot happen for a box that holds a piece of the triangle; keep the box as it is)
+#pragma unroll
+        for(int k = 0; k < 6; k++) it.b[k] = keep[k];
+        it.s--;
+      }
+    }
+    if(!cut || sp + 2 > VKRT_SPLIT_STACK)
+    {
+      if(EMIT)
+      {
+        refTri[base + n] = g;
+        const float pad = t.slop;
+#pragma unroll
+        for(int k = 0; k < 3; k++)
+        {
+          refBox[6 * (size_t)(base + n) + k] = fmaxf(it.b[k] - pad, t.full[k]);
+          refBox[6 * (size_t)(base + n) + 3 + k] = fminf(it.b[3 + k] + pad, t.full[3 + k]);
+        }
+      }
+      n++;
+      continue;
+    }
+    const float wa = fmaxf(L[3] - L[0], fmaxf(L[4] - L[1], L[5] - L[2])), wb = fmaxf(R[3] - R[0], fmaxf(R[4] - R[1], R[5] - R[2]));
+    const unsigned rest = it.s - 1u;
+    unsigned sa = (wa + wb) > 0.0f ? (unsigned)((float)rest * (wa / (wa + wb)) + 0.5f) : rest / 2u;
+    sa = min(sa, rest);
+    const unsigned sb = rest - sa;
+    Item A, B;
+#pragma unroll
+    for(int k = 0; k < 6; k++) { A.b[k] = L[k]; B.b[k] = R[k]; }
+    A.s = sa; B.s = sb;
+    if(sa >= sb) { stack[sp++] = A; stack[sp++] = B; }  // the smaller share is taken first
+    else { stack[sp++] = B; stack[sp++] = A; }
+  }
+  return n;
+}
+
+__global__ void k_split_priority(unsigned T, const float4* __restrict__ triU, const float* __restrict__ triBox, const unsigned* __restrict__ sceneBounds,
+                                 int watertight, float* __restrict__ prio)
+{
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= T)
+    return;
+  const SplitGrid G = loadSplitGrid(sceneBounds);
+  SplitTri t;
+  loadSplitTri(triU, triBox, g, watertight, t);
+  prio[g] = splitPriority(G, t);
+}
+
+// D with sum_t min(floor(D p_t), cap) <= budget, as large as 24 bisection steps find it (one workgroup; sums in a fixed order)
+__global__ __launch_bounds__(1024) void k_split_budget(unsigned T, const float* __restrict__ prio, unsigned budget, float dmax, float* __restrict__ Dout)
+{
+  __shared__ double red[1024];
+  __shared__ double total;
+  double acc = 0.0;
+  for(unsigned g = threadIdx.x; g < T; g += 1024u) acc += (double)prio[g];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for(unsigned off = 512u; off > 0u; off >>= 1)
+  {
+    if(threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if(threadIdx.x == 0) total = red[0];
+  __syncthreads();
+  const double sum = total;
+  if(!(sum > 0.0) || budget == 0u)
+  {
+    if(threadIdx.x == 0) *Dout = 0.0f;
+    return;
+  }
+  auto count = [&](float D) -> double {
+    __syncthreads();
+    double c = 0.0;
+    for(unsigned g = threadIdx.x; g < T; g += 1024u) c += (double)min((unsigned)(D * prio[g]), VKRT_SPLIT_MAX_PER_TRI);
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for(unsigned off = 512u; off > 0u; off >>= 1)
+    {
+      if(threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  float lo = (float)((double)budget / sum);  // floor() only lowers the sum: within the budget
+  if(count(lo) > (double)budget) lo = 0.0f;  // (float rounding of D itself)
+  float hi = fmaxf(lo, 1e-30f) * 2.0f;
+  for(int k = 0; k < 16 && count(hi) <= (double)budget; k++) { lo = hi; hi *= 2.0f; }
+  for(int k = 0; k < 24; k++)
+  {
+    const float mid = 0.5f * (lo + hi);
+    if(count(mid) <= (double)budget) lo = mid; else hi = mid;
+  }
+  if(threadIdx.x == 0) *Dout = fminf(lo, dmax);
+}
+
+template <bool EMIT>
+__global__ void k_split_refs(unsigned T, const float4* __restrict__ triU, const float* __restrict__ triBox, const unsigned* __restrict__ sceneBounds, int watertight,
+                             const float* __restrict__ prio, const float* __restrict__ D, unsigned* counts /*EMIT: exclusive offsets*/, unsigned* refTri,
+                             float* refBox)
+{
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  if(g >= T)
+    return;
+  const SplitGrid G = loadSplitGrid(sceneBounds);
+  SplitTri t;
+  loadSplitTri(triU, triBox, g, watertight, t);
+  const unsigned s = min((unsigned)(*D * prio[g]), VKRT_SPLIT_MAX_PER_TRI);
+  if(EMIT)
+    (void)splitTriangle<true>(G, t, s, g, counts[g], refTri, refBox);
+  else
+    counts[g] = splitTriangle<false>(G, t, s, g, 0u, nullptr, nullptr);
 }
 
 // ---- SAH top of the tree ------------------------------------------------------------------------------------------------
@@ -623,7 +961,7 @@ struct Temp
   } while(0)
 
 int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<vkrt_prim_mesh>& pm, const std::vector<vkrt_node>& nodes,
-                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide, bool ploc, bool watertight, bool dissolve)
+                      hipStream_t stream, LbvhResult& out, unsigned leafSize, bool wantWide, bool ploc, bool watertight, bool dissolve, unsigned splitPercent)
 {
   bool topSah = ploc;  // the FAST_TRACE device build re-builds its upper levels with SAH; the radix tree stays the pure fast build
   if(const char* e = getenv("VKRT_TOP_SAH"))  // test hook: force on / off for either builder
@@ -641,15 +979,17 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
     vertexOffset[n] = p.vertexOffset;
     material[n] = p.materialIndex;
   }
-  const uint32_t T = firstGid[instCount];
-  out.triCount = T;
+  const uint32_t triangles = firstGid[instCount];
+  out.triCount = triangles;
+  out.uniqueTris = triangles;
   out.rootRef = VKRT_TRAV_DONE;
-  LB_TRY(hipMalloc(&out.nodes, std::max<size_t>((size_t)(T > 1 ? T - 1 : 1) * 64, 64)));
-  LB_TRY(hipMalloc(&out.tris, std::max<size_t>((size_t)T * 48, 48)));
-  LB_TRY(hipMalloc(&out.triShade, std::max<size_t>((size_t)T * 16, 16)));
-  out.nodeCount = T > 1 ? T - 1 : 0;
-  if(T == 0)
+  if(triangles == 0)
+  {
+    LB_TRY(hipMalloc(&out.nodes, 64));
+    LB_TRY(hipMalloc(&out.tris, 48));
+    LB_TRY(hipMalloc(&out.triShade, 16));
     return VKRT_OK;
+  }
 
   Temp tmp;
   uint32_t *dFirstGid, *dFirstIndex, *dVertexOffset;
@@ -666,21 +1006,81 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
   float4* triU;
   float* triBox;
   unsigned* bounds;
+  LB_TRY(tmp.alloc(&triU, (size_t)triangles * 3));
+  LB_TRY(tmp.alloc(&triBox, (size_t)triangles * 6));
+  LB_TRY(tmp.alloc(&bounds, 8));
+  const unsigned initB[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+  LB_TRY(hipMemcpyAsync(bounds, initB, sizeof initB, hipMemcpyHostToDevice, stream));
+
+  const unsigned B = 256;
+  FlatArgs A{sc.positions, sc.indices, sc.instances, dFirstGid, dFirstIndex, dVertexOffset, instCount, triangles};
+  hipLaunchKernelGGL(k_flatten, dim3((triangles + B - 1) / B), dim3(B), 0, stream, A, watertight ? 1 : 0, triU, triBox, bounds);
+  LB_TRY(hipGetLastError());
+
+  // ---- triangle pre-splitting: T = references (>= triangles), refTri / refBox replace the identity / triBox ------------------
+  uint32_t T = triangles;
+  const unsigned* refTri = nullptr;
+  const float* refBox = triBox;
+  const unsigned budget = (unsigned)std::min<uint64_t>((uint64_t)triangles * splitPercent / 100u, 0x3fffffffu);
+  if(budget > 0u && triangles > 1u)
+  {
+    const unsigned G3 = (triangles + B - 1) / B;
+    float *prio, *dD;
+    unsigned *counts, *offsets;
+    LB_TRY(tmp.alloc(&prio, triangles));
+    LB_TRY(tmp.alloc(&dD, 4));
+    LB_TRY(tmp.alloc(&counts, (size_t)triangles + 1));
+    LB_TRY(tmp.alloc(&offsets, (size_t)triangles + 1));
+    hipLaunchKernelGGL(k_split_priority, dim3(G3), dim3(B), 0, stream, triangles, (const float4*)triU, (const float*)triBox, (const unsigned*)bounds, watertight ? 1 : 0, prio);
+    float dmax = INFINITY;
+    if(const char* e = getenv("VKRT_SPLIT_DMAX"))  // test hook: cap of the priority scale D (splits per unit of priority)
+      dmax = (float)atof(e);
+    hipLaunchKernelGGL(k_split_budget, dim3(1), dim3(1024), 0, stream, triangles, (const float*)prio, budget, dmax, dD);
+    LB_TRY(hipMemsetAsync(counts + triangles, 0, 4, stream));
+    hipLaunchKernelGGL((k_split_refs<false>), dim3(G3), dim3(B), 0, stream, triangles, (const float4*)triU, (const float*)triBox, (const unsigned*)bounds,
+                       watertight ? 1 : 0, (const float*)prio, (const float*)dD, counts, (unsigned*)nullptr, (float*)nullptr);
+    LB_TRY(hipGetLastError());
+    size_t scanBytes = 0;
+    LB_TRY(rocprim::exclusive_scan(nullptr, scanBytes, counts, offsets, 0u, (size_t)triangles + 1, rocprim::plus<unsigned>(), stream));
+    void* scanTmp;
+    LB_TRY(tmp.alloc((char**)&scanTmp, scanBytes));
+    LB_TRY(rocprim::exclusive_scan(scanTmp, scanBytes, counts, offsets, 0u, (size_t)triangles + 1, rocprim::plus<unsigned>(), stream));
+    unsigned total = 0;
+    LB_TRY(hipMemcpyAsync(&total, offsets + triangles, 4, hipMemcpyDeviceToHost, stream));
+    LB_TRY(hipStreamSynchronize(stream));
+    if(total < triangles || total > triangles + budget)
+    {
+      out.error = "triangle pre-splitting: reference count out of range (internal error)";
+      return VKRT_ERR_HIP;
+    }
+    if(total > triangles)
+    {
+      unsigned* rt;
+      float* rb;
+      LB_TRY(tmp.alloc(&rt, total));
+      LB_TRY(tmp.alloc(&rb, (size_t)total * 6));
+      hipLaunchKernelGGL((k_split_refs<true>), dim3(G3), dim3(B), 0, stream, triangles, (const float4*)triU, (const float*)triBox, (const unsigned*)bounds,
+                         watertight ? 1 : 0, (const float*)prio, (const float*)dD, offsets, rt, rb);
+      LB_TRY(hipGetLastError());
+      T = total;
+      refTri = rt;
+      refBox = rb;
+    }
+  }
+  out.triCount = T;
+  LB_TRY(hipMalloc(&out.nodes, std::max<size_t>((size_t)(T > 1 ? T - 1 : 1) * 64, 64)));
+  LB_TRY(hipMalloc(&out.tris, std::max<size_t>((size_t)T * 48, 48)));
+  LB_TRY(hipMalloc(&out.triShade, std::max<size_t>((size_t)T * 16, 16)));
+  out.nodeCount = T > 1 ? T - 1 : 0;
+
   unsigned long long *keysA, *keysB;
   unsigned *valsA, *valsB;
-  LB_TRY(tmp.alloc(&triU, (size_t)T * 3));
-  LB_TRY(tmp.alloc(&triBox, (size_t)T * 6));
-  LB_TRY(tmp.alloc(&bounds, 8));
   LB_TRY(tmp.alloc(&keysA, T));
   LB_TRY(tmp.alloc(&keysB, T));
   LB_TRY(tmp.alloc(&valsA, T));
   LB_TRY(tmp.alloc(&valsB, T));
-  const unsigned initB[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
-  LB_TRY(hipMemcpyAsync(bounds, initB, sizeof initB, hipMemcpyHostToDevice, stream));
-
-  const unsigned B = 256, G = (T + B - 1) / B;
-  FlatArgs A{sc.positions, sc.indices, sc.instances, dFirstGid, dFirstIndex, dVertexOffset, instCount, T};
-  hipLaunchKernelGGL(k_flatten, dim3(G), dim3(B), 0, stream, A, watertight ? 1 : 0, triU, triBox, bounds);
+  const unsigned G = (T + B - 1) / B;
+  triBox = const_cast<float*>(refBox);  // from here on "triangle" means reference -- one leaf of the tree -- and triBox its box
   hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, T, (const float*)triBox, (const unsigned*)bounds, keysA, valsA);
   LB_TRY(hipGetLastError());
 
@@ -691,7 +1091,8 @@ int build_lbvh_device(const DevScene& sc, uint32_t instCount, const std::vector<
   LB_TRY(rocprim::radix_sort_pairs(sortTmp, sortBytes, keysA, keysB, valsA, valsB, (size_t)T, 0, 63, stream));
   const unsigned* order = valsB;
 
-  hipLaunchKernelGGL(k_pack, dim3(G), dim3(B), 0, stream, T, order, (const float4*)triU, (float4*)out.tris, A, (const int*)dMaterial, (uint4*)out.triShade, dissolve ? sc.materials : (const DevMaterial*)nullptr);
+  hipLaunchKernelGGL(k_pack, dim3(G), dim3(B), 0, stream, T, order, (const float4*)triU, (float4*)out.tris, A, (const int*)dMaterial, (uint4*)out.triShade,
+                     dissolve ? sc.materials : (const DevMaterial*)nullptr, refTri);
   LB_TRY(hipGetLastError());
 
   if(T <= kLeaf)

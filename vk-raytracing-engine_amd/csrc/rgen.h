@@ -72,7 +72,7 @@ VKRT_DEV void storePixel(const TraceParams& P, const LaneState& L)
 {
   const f3 res = L.hitValues / (float)P.pc.samples;
   float4* dst = (float4*)P.image + ((size_t)L.lrow * P.fullW + L.px);
-  if(P.pc.frame > 0)
+  if(P.pc.frame > 0 && !(P.flags & VKRT_FLAG_STORE_STAGED))  // (a frame in flight leaves `res` in its staging plane; blendPixel follows in frame order)
   {
     const float a = 1.0f / (float)(P.pc.frame + 1);
     const float4 old = *dst;
@@ -81,6 +81,20 @@ VKRT_DEV void storePixel(const TraceParams& P, const LaneState& L)
   }
   else
     *dst = make_float4(res.x, res.y, res.z, 1.0f);
+}
+
+// raytrace.rgen:136-145 for a pixel whose value `res` was staged (frames in flight): same operations as storePixel's
+VKRT_DEV void blendPixel(float4* dst, float4 staged, int frame)
+{
+  if(frame > 0)
+  {
+    const float a = 1.0f / (float)(frame + 1);
+    const float4 old = *dst;
+    const f3 m = glsl_mix(mk3(old.x, old.y, old.z), mk3(staged.x, staged.y, staged.z), a);
+    *dst = make_float4(m.x, m.y, m.z, 1.0f);
+  }
+  else
+    *dst = make_float4(staged.x, staged.y, staged.z, 1.0f);
 }
 
 // After the closest-hit ray of the current segment: run rchit / rmiss (raytrace.rgen:64-75).

@@ -142,9 +142,12 @@ VKRT_DEV bool tri_test_wt(const WtRay& R, f3 o, f3 p0, f3 p1, f3 p2, float& t, f
 }
 
 // Compile-time "triangle mode" TM of every traversal: bit 0 = the watertight test (VKRT_OPT_WATERTIGHT), bit 1 = the any-hit alpha /
-// dissolve stage (VKRT_OPT_ANYHIT_DISSOLVE).  TM = 0 is the product default and compiles to exactly the code it was before.
+// dissolve stage (VKRT_OPT_ANYHIT_DISSOLVE), bit 2 = the records may carry the stage's flag in their id word although this walk
+// treats every triangle as opaque (the ray-cast G-buffer on a scene built for the stage): the id is masked, no hit is ignored.
+// TM = 0 is the product default and compiles to exactly the code it was before.
 #define VKRT_TM_WATERTIGHT 1
 #define VKRT_TM_DISSOLVE 2
+#define VKRT_TM_MASKID 4
 
 // per-ray constants + one entry point on a 48-byte record (a, b, c)
 template <bool WT> struct TriRay;
@@ -174,9 +177,9 @@ template <> struct TriRay<true>
 // invocations, so the decision is made a pure function of (ray, triangle): results stay independent of the tree and of the
 // schedule.  prd.seed is not advanced.)  Same function in oracle/oracle.cpp (dissolveIgnores).
 template <int TM>
-VKRT_DEV int tri_gid(float idWord)  // the flattened triangle id of a record (bit 31 = dissolve flag when the stage is compiled in)
+VKRT_DEV int tri_gid(float idWord)  // the flattened triangle id of a record (bit 31 = dissolve flag when the records can carry it)
 {
-  return (TM & VKRT_TM_DISSOLVE) ? (__float_as_int(idWord) & 0x7fffffff) : __float_as_int(idWord);
+  return (TM & (VKRT_TM_DISSOLVE | VKRT_TM_MASKID)) ? (__float_as_int(idWord) & 0x7fffffff) : __float_as_int(idWord);
 }
 template <int TM>
 VKRT_DEV bool anyhit_ignores(const DevScene& sc, unsigned slot, float idWord, uint32_t raySeed)

@@ -14,10 +14,6 @@
 #pragma once
 #include "traverse_wide.h"
 
-#ifndef VKRT_EXP
-#define VKRT_EXP 0  // compile-time experiments of the sharing wave (profiles/r03_experiments.md #80, #81); 0 = the product
-#endif
-
 // per-wave LDS block: 64 x (u64 key, slot, u, v, donor lane by rank)
 #define VKRT_SHARE_LDS_WORDS 384
 struct ShareRes
@@ -49,7 +45,7 @@ VKRT_DEV ShareRes shareRes(int* lds320)
 // stk: this lane's stack column (stride 64 entries), res: the wave's ShareRes block.
 template <bool COUNT, bool ANYHIT, int TM = 0>
 VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, float tmin, float tmax, uint2* stk, ShareRes res, RayHit& hit,
-                                   TravCount& tc, uint32_t raySeed = 0u, vkrt_lds_float4* topLds = nullptr)
+                                   TravCount& tc, uint32_t raySeed = 0u)
 {
   TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> tr;
   tr.set(d);
@@ -146,65 +142,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
     bool found = false;  // this lane has a candidate hit to publish
     float ct = 0.0f, cu = 0.0f, cv = 0.0f;
     int cslot = -1, cgid = 0;
-    int pubOwner = owner;  // the ray the candidate belongs to (VKRT_EXP 2: may be the ray of an adopted triangle)
     shareSync();  // results published in the previous step are visible to every lane of the ray
-#if VKRT_EXP == 2
-    // ---- experiment #81: triangle hand-off.  A lane with two or more pending triangles gives its SECOND one to a lane that has no
-    // triangle of its own to test in this step (idle, or busy with node work only); the taker tests it against the donor's ray and
-    // publishes for the donor's ray.  A leaf's 2-3 triangles are then tested in one wave step instead of 2-3.
-    bool adopted = false;
-    {
-      const bool offers = busy && (T.y & (T.y - 1u)) != 0u;
-      const bool freeLane = !(busy && T.y != 0u);
-      const unsigned long long offerMask = __ballot(offers), freeMask = __ballot(freeLane);
-      if(offerMask != 0ull && freeMask != 0ull)
-      {
-        const unsigned n = min((unsigned)__popcll(offerMask), (unsigned)__popcll(freeMask));
-        const unsigned giveRank = (unsigned)__popcll(offerMask & below), takeRank = (unsigned)__popcll(freeMask & below);
-        const bool gives = offers && giveRank < n, takes = freeLane && takeRank < n;
-        unsigned hs = 0u;
-        if(gives)
-        {
-          const unsigned rest = T.y & (T.y - 1u);              // without the first pending triangle (the donor tests that one itself)
-          const unsigned i2 = (unsigned)__ffs((int)rest) - 1u;
-          T.y &= ~(1u << i2);
-          hs = T.x + i2;
-          res.donor[giveRank] = lane;
-        }
-        shareSync();
-        const int src = takes ? res.donor[takeRank] : lane;
-        const unsigned hslot = (unsigned)__shfl((int)hs, src);
-        const float ox = __shfl(o.x, src), oy = __shfl(o.y, src), oz = __shfl(o.z, src);
-        const float dx = __shfl(d.x, src), dy = __shfl(d.y, src), dz = __shfl(d.z, src);
-        const float tm = __shfl(tmax, src);
-        const int ow = __shfl(owner, src);
-        if(takes)
-        {
-          const f3 ho = mk3(ox, oy, oz), hd = mk3(dx, dy, dz);
-          const float4* __restrict__ tp = tris + (size_t)hslot * VKRT_TRI_QUADS;
-          const float4 a = tp[0], b = tp[1], c = tp[2];
-          if(COUNT) tc.tris++;
-          TriRay<(TM & VKRT_TM_WATERTIGHT) != 0> htr;
-          htr.set(hd);
-          float t, u, v;
-          if(htr.hit(ho, hd, a, b, c, t, u, v) && t > tmin)
-          {
-            if(ANYHIT)
-            {
-              if(t < tm) { found = true; ct = t; cslot = (int)hslot; pubOwner = ow; adopted = true; }
-            }
-            else
-            {
-              const unsigned long long k = __hip_atomic_load(&res.key[ow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              const float rt = __uint_as_float((unsigned)(k >> 32));
-              const int rg = (int)(unsigned)k, gid = tri_gid<TM>(c.y);
-              if(t < rt || (t == rt && gid < rg)) { found = true; ct = t; cu = u; cv = v; cslot = (int)hslot; cgid = gid; pubOwner = ow; adopted = true; }
-            }
-          }
-        }
-      }
-    }
-#endif
     if(busy)
     {
       float bt = tmax;
@@ -225,16 +163,9 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           T.y &= T.y - 1u;
           const unsigned s = T.x + i;
           const float4* __restrict__ tp = tris + (size_t)s * VKRT_TRI_QUADS;
-#if VKRT_EXP == 18
-          // experiment #104: triangle records (12.6 MB, more than an XCD's L2 holds) fetched non-temporally so that the nodes stay resident
-          const vkrt_v4f na = __builtin_nontemporal_load((const vkrt_v4f*)&tp[0]), nb = __builtin_nontemporal_load((const vkrt_v4f*)&tp[1]),
-                         nc = __builtin_nontemporal_load((const vkrt_v4f*)&tp[2]);
-          const float4 a = make_float4(na.x, na.y, na.z, na.w), b = make_float4(nb.x, nb.y, nb.z, nb.w), c = make_float4(nc.x, nc.y, nc.z, nc.w);
-#else
           const float4 a = tp[0];
           const float4 b = tp[1];
           const float4 c = tp[2];
-#endif
           if(COUNT)
           {
             tc.tris++;
@@ -280,7 +211,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
               VKRT_TRAV_FAULT(sc);
           }
           uint2 Tn;
-          w8_test_children<COUNT, VKRT_TOP_NODES>(nodes, child, o, id, octinv, px, py, pz, tmin, bt, G, Tn, tc, topLds);
+          w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bt, G, Tn, tc);
           if(Tn.y != 0u)
           {
             if(T.y != 0u)
@@ -315,21 +246,9 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
         bool triStep = true;
         if(sc.triThreshold > 1u)
           triStep = (unsigned)__popcll(__ballot(T.y != 0u)) >= sc.triThreshold || __ballot((G.y & 0xff000000u) != 0u) == 0ull;
-#if VKRT_EXP == 2
-        if(T.y != 0u && triStep && !adopted)  // (a lane that tested an adopted triangle in this step keeps its own for the next one)
-#else
         if(T.y != 0u && triStep && !(ANYHIT && found))
-#endif
           testOne();
-#if VKRT_EXP == 1
-        if(T.y != 0u && triStep && !(ANYHIT && found))  // experiment #80: a second triangle of the pending group in the same step
-          testOne();
-#endif
-#if VKRT_EXP == 2
-        if(ANYHIT && found && !adopted)
-#else
         if(ANYHIT && found)
-#endif
           finished = true;
         else if((G.y & 0xff000000u) == 0u && T.y == 0u && nPost == 0)
           finished = true;  // (sp == sb here: the refill above would have popped otherwise)
@@ -346,17 +265,17 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
     if(found)
     {
       if(ANYHIT)
-        __hip_atomic_store(&res.slot[pubOwner], cslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&res.slot[owner], cslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       else
       {
         // (t bits, triangle id) is unique per candidate, so "the minimum is mine" identifies exactly one winner among the
         // lanes publishing for this ray in this step; it alone writes the payload.  Keys only decrease.
         const unsigned long long mine = ((unsigned long long)__float_as_uint(ct) << 32) | (unsigned)cgid;
-        __hip_atomic_fetch_min(&res.key[pubOwner], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_min(&res.key[owner], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         shareSync();  // every lane's minimum has been applied before anyone checks who won
-        if(__hip_atomic_load(&res.key[pubOwner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == mine)
+        if(__hip_atomic_load(&res.key[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == mine)
         {
-          res.slot[pubOwner] = cslot; res.u[pubOwner] = cu; res.v[pubOwner] = cv;
+          res.slot[owner] = cslot; res.u[owner] = cu; res.v[owner] = cv;
         }
       }
     }

@@ -16,10 +16,7 @@
 #include "wide_node.h"
 
 typedef float vkrt_v4f __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(3))) vkrt_v4f vkrt_lds_float4;  // LDS-qualified: ds_read, not a flat load through the memory path
 VKRT_DEV float ubyte_f32(unsigned w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
-typedef _Float16 vkrt_half2 __attribute__((ext_vector_type(2)));
-VKRT_DEV float half_f32(unsigned w, int k) { const vkrt_half2 v = __builtin_bit_cast(vkrt_half2, w); return (float)(k ? v.y : v.x); }
 
 // Resumable per-lane traversal state: one w8_iterate() = take the nearest pending child node of the
 // current group, test its 8 children, intersect the triangles the ray's boxes touched, then pop if the
@@ -57,37 +54,12 @@ VKRT_DEV void w8_begin(const DevScene& sc, W8State<TM>& S, f3 o, f3 d, float tma
 
 // Test the 8 children of wide node `child` against the ray: G = (child base, hit internal children | imask),
 // T = (triangle base, 24-bit mask of the leaf triangles whose boxes the ray touched).
-// TOP > 0: nodes [0, TOP) -- the root and its children, the nodes every walk starts with -- are read from the wave's copy in LDS
-// (topLds) instead of through the vector memory path (tools/gather_microbench.hip: a per-lane node fetch costs that path ~48 cycles
-// per instruction, an LDS read 8)
-template <bool COUNT, int TOP = 0>
+template <bool COUNT>
 VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child, f3 o, f3 id, unsigned octinv, bool px, bool py, bool pz, float tmin,
-                               float bestT_in, uint2& G, uint2& T, TravCount& tc, vkrt_lds_float4* topLds = nullptr)
+                               float bestT_in, uint2& G, uint2& T, TravCount& tc)
 {
   const float4* __restrict__ np = nodes + (size_t)child * VKRT_WNODE_QUADS;  // one 64-bit address, immediate offsets
-#if !VKRT_WNODE_F16
-  float4 q0, q1, q2, q3, q4;
-  if(TOP > 0 && child < (unsigned)TOP)
-  {
-    vkrt_lds_float4* lp = topLds + child * VKRT_WNODE_QUADS;
-    const vkrt_v4f a0 = lp[0], a1 = lp[1], a2 = lp[2], a3 = lp[3], a4 = lp[4];
-    q0 = make_float4(a0.x, a0.y, a0.z, a0.w); q1 = make_float4(a1.x, a1.y, a1.z, a1.w); q2 = make_float4(a2.x, a2.y, a2.z, a2.w);
-    q3 = make_float4(a3.x, a3.y, a3.z, a3.w); q4 = make_float4(a4.x, a4.y, a4.z, a4.w);
-  }
-  else
-  {
-    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3]; q4 = np[4];
-  }
-#else
-  const float4 q0 = np[0];
-  const float4 q1 = np[1];
-#endif
-#if VKRT_WNODE_F16
-  // near / far plane quads picked by the sign of the ray direction at the LOAD (a per-lane quad index) instead of afterwards
-  const float4 nxq = np[px ? 2 : 5], fxq = np[px ? 5 : 2];
-  const float4 nyq = np[py ? 3 : 6], fyq = np[py ? 6 : 3];
-  const float4 nzq = np[pz ? 4 : 7], fzq = np[pz ? 7 : 4];
-#endif
+  const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
   if(COUNT)
   {
     tc.nodes++;
@@ -114,15 +86,6 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
   const float fsx = asx * VKRT_BOX_PAD_REL, fsy = asy * VKRT_BOX_PAD_REL, fsz = asz * VKRT_BOX_PAD_REL;
   const float nsx = asx * VKRT_BOX_PAD_NEAR, nsy = asy * VKRT_BOX_PAD_NEAR, nsz = asz * VKRT_BOX_PAD_NEAR;  // near planes: t * (1 - 4e-5)
   // quantised planes, near/far by ray direction sign
-#if VKRT_WNODE_F16
-  const unsigned nx[4] = {__float_as_uint(nxq.x), __float_as_uint(nxq.y), __float_as_uint(nxq.z), __float_as_uint(nxq.w)};
-  const unsigned fx[4] = {__float_as_uint(fxq.x), __float_as_uint(fxq.y), __float_as_uint(fxq.z), __float_as_uint(fxq.w)};
-  const unsigned ny[4] = {__float_as_uint(nyq.x), __float_as_uint(nyq.y), __float_as_uint(nyq.z), __float_as_uint(nyq.w)};
-  const unsigned fy[4] = {__float_as_uint(fyq.x), __float_as_uint(fyq.y), __float_as_uint(fyq.z), __float_as_uint(fyq.w)};
-  const unsigned nz[4] = {__float_as_uint(nzq.x), __float_as_uint(nzq.y), __float_as_uint(nzq.z), __float_as_uint(nzq.w)};
-  const unsigned fz[4] = {__float_as_uint(fzq.x), __float_as_uint(fzq.y), __float_as_uint(fzq.z), __float_as_uint(fzq.w)};
-#define VKRT_WN_PLANE(a, w, k) half_f32((a)[2 * (w) + ((k) >> 1)], (k) & 1)
-#else
   const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
   const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
   const unsigned hy0 = __float_as_uint(q4.x), hy1 = __float_as_uint(q4.y), hz0 = __float_as_uint(q4.z), hz1 = __float_as_uint(q4.w);
@@ -130,7 +93,6 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
   const unsigned ny[2] = {py ? ly0 : hy0, py ? ly1 : hy1}, fy[2] = {py ? hy0 : ly0, py ? hy1 : ly1};
   const unsigned nz[2] = {pz ? lz0 : hz0, pz ? lz1 : hz1}, fz[2] = {pz ? hz0 : lz0, pz ? hz1 : lz1};
 #define VKRT_WN_PLANE(a, w, k) ubyte_f32((a)[w], k)
-#endif
   const float bestT = bestT_in;
   unsigned hitmask = 0u;
 #pragma unroll

@@ -24,6 +24,8 @@
 #define VKRT_TRI_THRESHOLD_DEFAULT 1
 #define VKRT_WF_SHARE_DEFAULT 16
 #define VKRT_WF_SHARE_FLAGS_DEFAULT 9
+#define VKRT_WF_FRAMES_IN_FLIGHT_DEFAULT 3
+#define VKRT_SPLIT_BUDGET_DEFAULT 0
 #include "lbvh.h"
 
 namespace {
@@ -83,7 +85,9 @@ struct vkrt_scene
   WfTiming wfTiming{};
   bool wfTimed = false;
   // execution options (include/vkrt.h vkrt_option); index = option id
-  int opt[VKRT_OPT_LAST + 1] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1, 0, 0, 0};
+  std::vector<hipEvent_t> wfPool;  // events ordering the lanes of one call (kernels.h WfAsync::pool)
+  int opt[VKRT_OPT_LAST + 1] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1, 0, 0, 0,
+                                VKRT_WF_FRAMES_IN_FLIGHT_DEFAULT, VKRT_SPLIT_BUDGET_DEFAULT};
   bool hasLargeTriangles = false;  // some instanced triangle covers more than 1 % of the largest face of the scene's box (any-hit order heuristic)
   bool wavefront = true;  // execution mode the acceleration structure was built for (opt[VKRT_OPT_MODE] at vkrt_accel_build)
 };
@@ -198,7 +202,8 @@ int clampOption(int option, int v)
   switch(option)
   {
     case VKRT_OPT_MODE: case VKRT_OPT_BVH_LAYOUT: return v ? 1 : 0;
-    case VKRT_OPT_WF_SUBFRAMES: return std::max(1, std::min(VKRT_WF_MAX_SUBFRAMES, v));
+    case VKRT_OPT_WF_SUBFRAMES: case VKRT_OPT_WF_FRAMES_IN_FLIGHT: return std::max(1, std::min(VKRT_WF_MAX_LANES, v));
+    case VKRT_OPT_SPLIT_BUDGET: return std::max(0, std::min(100, v));
     case VKRT_OPT_WF_TRAV_BLOCK: return v == 256 ? 256 : v == 128 ? 128 : 64;
     case VKRT_OPT_WF_SHARE: return std::max(0, std::min(64, v));
     case VKRT_OPT_TRI_THRESHOLD: return std::max(0, std::min(65, v));
@@ -220,7 +225,8 @@ void optionsFromEnvironment(vkrt_scene* s)
                                                           {"VKRT_WF_SHARE_PERIOD", VKRT_OPT_WF_SHARE_PERIOD}, {"VKRT_WF_SHARE_FLAGS", VKRT_OPT_WF_SHARE_FLAGS},
                                                           {"VKRT_GBUFFER_MIPS", VKRT_OPT_GBUFFER_MIPS}, {"VKRT_WATERTIGHT", VKRT_OPT_WATERTIGHT},
                                                           {"VKRT_SKIP_DEAD_SHADOW_RAYS", VKRT_OPT_SKIP_DEAD_SHADOW_RAYS},
-                                                          {"VKRT_ANYHIT_DISSOLVE", VKRT_OPT_ANYHIT_DISSOLVE}};
+                                                          {"VKRT_ANYHIT_DISSOLVE", VKRT_OPT_ANYHIT_DISSOLVE}, {"VKRT_WF_FRAMES_IN_FLIGHT", VKRT_OPT_WF_FRAMES_IN_FLIGHT},
+                                                          {"VKRT_SPLIT_BUDGET", VKRT_OPT_SPLIT_BUDGET}};
   for(const auto& k : ints)
     if((e = getenv(k.name)))
       s->opt[k.option] = clampOption(k.option, atoi(e));
@@ -241,30 +247,54 @@ int setDevice(const vkrt_scene* s)
   return VKRT_OK;
 }
 
-// Working set of the wavefront pipeline for `paths` path records (whole 8x8 tiles of the shard) + the internal streams
-// of the sub-frame pipeline.  Growing it is the only place a trace call may synchronise with the host (vkrt_reserve).
-int ensureWorkingSet(vkrt_scene* s, uint32_t paths, hipStream_t stream)
+// Working set of the wavefront pipeline for `paths` path records (whole 8x8 tiles of the shard) in each of `groups` frame groups
+// (frames in flight) + the internal streams of the lanes.  Growing it is the only place a trace call may synchronise with the
+// host (vkrt_reserve).
+int ensureWorkingSet(vkrt_scene* s, uint32_t paths, int groups, hipStream_t stream)
 {
-  if(!s->wfMem || s->wf.capacity < paths)
+  groups = std::max(1, std::min(VKRT_WF_MAX_LANES, groups));
+  if(!s->wfMem || s->wf.capacity < paths || (int)s->wf.groups < groups)
   {
     HIP_TRY(hipStreamSynchronize(stream));  // an earlier frame may still be using the smaller buffer
     if(s->wfMem) (void)hipFree(s->wfMem);
     s->wfMem = nullptr;
-    HIP_TRY(hipMalloc(&s->wfMem, vkrt_wf_state_bytes(paths)));
-    vkrt_wf_carve(s->wfMem, paths, &s->wf);
+    paths = std::max(paths, s->wf.capacity);
+    groups = std::max(groups, (int)s->wf.groups);
+    s->wf = WfBuffers{};
+    HIP_TRY(hipMalloc(&s->wfMem, vkrt_wf_state_bytes(paths, groups)));
+    vkrt_wf_carve(s->wfMem, paths, groups, &s->wf);
   }
   if(s->wfAsync.count == 0)
   {
     HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.fork, hipEventDisableTiming));
-    for(int j = 0; j < VKRT_WF_MAX_SUBFRAMES; j++)
+    for(int j = 0; j < VKRT_WF_MAX_LANES; j++)
     {
       HIP_TRY(hipStreamCreateWithFlags(&s->wfAsync.streams[j], hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&s->wfAsync.join[j], hipEventDisableTiming));
     }
-    s->wfAsync.count = VKRT_WF_MAX_SUBFRAMES;
+    s->wfAsync.count = VKRT_WF_MAX_LANES;
   }
   return VKRT_OK;
 }
+
+// events that order the lanes of a call of `frames` frames (created once, kept; no device synchronisation)
+int ensureEventPool(vkrt_scene* s, int frames)
+{
+  const size_t want = (size_t)vkrt_wf_pool_events(frames, VKRT_WF_MAX_LANES);
+  while(s->wfPool.size() < want)
+  {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    s->wfPool.push_back(e);
+  }
+  s->wfAsync.pool = s->wfPool.data();
+  s->wfAsync.poolSize = (int)s->wfPool.size();
+  return VKRT_OK;
+}
+
+// frames a call keeps in flight: the option, but never more than the call has
+int framesInFlight(const vkrt_scene* s, int frames) { return std::max(1, std::min(s->opt[VKRT_OPT_WF_FRAMES_IN_FLIGHT], frames)); }
+#define VKRT_FRAMES_PER_BATCH 32  // a longer call is rendered as batches of this many frames (bounds the event pool)
 
 }  // namespace
 
@@ -456,6 +486,7 @@ void vkrt_scene_destroy(vkrt_scene* s)
     }
   }
   for(hipEvent_t e : s->wfEvents) (void)hipEventDestroy(e);
+  for(hipEvent_t e : s->wfPool) (void)hipEventDestroy(e);
   if(s->evStart) (void)hipEventDestroy(s->evStart);
   if(s->evStop) (void)hipEventDestroy(s->evStop);
   delete s;
@@ -507,7 +538,11 @@ int vkrt_reserve(vkrt_scene* s, const vkrt_shard* shard, void* hip_stream)
   const bool wavefront = s->built ? s->wavefront : useWavefront(s);
   if(tiles == 0 || !wavefront)
     return VKRT_OK;  // the megakernel keeps its state in registers / LDS
-  return ensureWorkingSet(s, (uint32_t)tiles * 64u, (hipStream_t)hip_stream);
+  // frame groups: what a vkrt_pathtrace_frames call would keep in flight under the current options
+  int rc2 = ensureWorkingSet(s, (uint32_t)tiles * 64u, s->opt[VKRT_OPT_WF_FRAMES_IN_FLIGHT], (hipStream_t)hip_stream);
+  if(rc2 == VKRT_OK)
+    rc2 = ensureEventPool(s, VKRT_FRAMES_PER_BATCH);
+  return rc2;
 }
 
 int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
@@ -530,20 +565,25 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
   s->info = vkrt_accel_info{};
   s->info.build_flags = wantPloc ? VKRT_BUILD_PLOC_GPU : wantLbvh ? VKRT_BUILD_LBVH_GPU : VKRT_BUILD_SAH_HOST;
   s->wavefront = useWavefront(s);
-  const bool watertight = s->opt[VKRT_OPT_WATERTIGHT] != 0, dissolve = s->opt[VKRT_OPT_ANYHIT_DISSOLVE] != 0;
-  if((watertight || dissolve) && useWavefront(s) && s->opt[VKRT_OPT_WF_TRAV_BLOCK] != 64)
+  const bool watertight = s->opt[VKRT_OPT_WATERTIGHT] != 0;
+  if((watertight || s->opt[VKRT_OPT_ANYHIT_DISSOLVE] != 0) && useWavefront(s) && s->opt[VKRT_OPT_WF_TRAV_BLOCK] != 64)
     return fail(VKRT_ERR_UNSUPPORTED, "VKRT_OPT_WATERTIGHT / VKRT_OPT_ANYHIT_DISSOLVE are built for the default 64-thread traversal workgroups "
                 "(VKRT_OPT_WF_TRAV_BLOCK = %d)", s->opt[VKRT_OPT_WF_TRAV_BLOCK]);
-  s->dev.watertight = watertight ? 1u : 0u;
-  s->dev.dissolve = dissolve ? 1u : 0u;
-  // per instance: is its material non-opaque (dissolve = pbrBaseColorFactor.a < 1)?  Only consulted with the any-hit stage on.
+  // per instance: is its material non-opaque (dissolve = pbrBaseColorFactor.a < 1)?  The stage is compiled into the traversal only when
+  // the scene has such an instance: without one no record carries the flag, the stage could never ignore a hit, and the flag test
+  // and seed load per ray would cost 3.8 % for nothing (profiles/r03_options/ANYHIT_DISSOLVE.json)
   std::vector<uint8_t> instDissolves;
-  if(dissolve)
+  bool dissolve = false;
+  if(s->opt[VKRT_OPT_ANYHIT_DISSOLVE] != 0)
     for(const vkrt_node& n : s->nodes)
     {
       const int32_t m = std::max(0, s->primMeshes[(size_t)n.primMesh].materialIndex);
-      instDissolves.push_back(s->materialAlpha[(size_t)m] < 1.0f ? 1 : 0);
+      const bool nonOpaque = s->materialAlpha[(size_t)m] < 1.0f && s->primMeshes[(size_t)n.primMesh].indexCount >= 3u;
+      instDissolves.push_back(nonOpaque ? 1 : 0);
+      dissolve = dissolve || nonOpaque;
     }
+  s->dev.watertight = watertight ? 1u : 0u;
+  s->dev.dissolve = dissolve ? 1u : 0u;
   const std::vector<uint8_t>* dissolvePtr = dissolve ? &instDissolves : nullptr;
 
   if(wantSah)
@@ -620,11 +660,12 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     // binary tree keeps one triangle per leaf and is collapsed into wide8 nodes by the same SAH-optimal DP as the SAH
     // path -- on the device too (wide_collapse.hip); nothing but four statistics words comes back to the host.
     // VKRT_BUILD_PLOC_GPU: same pipeline with the radix tree replaced by locally-ordered clustering (ploc.hip)
-    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide, wantPloc, watertight, dissolve);
+    rc = vkrt::build_lbvh_device(s->dev, (uint32_t)s->nodes.size(), s->primMeshes, s->nodes, stream, r, wide ? 1u : 4u, wide, wantPloc, watertight, dissolve,
+                                 (unsigned)s->opt[VKRT_OPT_SPLIT_BUDGET]);
     if(rc != VKRT_OK)
       return fail(rc, "%s build failed: %s", wantPloc ? "PLOC" : "LBVH", r.error.c_str());
-    s->info.triangle_count = r.triCount;
-    s->dev.triCount = r.triCount;
+    s->info.triangle_count = r.uniqueTris;
+    s->dev.triCount = r.triCount;  // slots: a pre-split triangle occupies one per reference
     if(wide && r.hasWide)
     {
       (void)hipFree(r.nodes); (void)hipFree(r.tris); (void)hipFree(r.triShade);
@@ -780,7 +821,8 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     }
     s->hasLargeTriangles = face > 0.0 && maxArea > 0.01 * face;
   }
-  s->dev.stepLimit = 4u * (s->info.node_count + s->info.triangle_count) + 64u;
+  s->info.reference_count = s->dev.triCount;
+  s->dev.stepLimit = 4u * (s->info.node_count + s->dev.triCount) + 64u;
   s->dev.triThreshold = 0;
   s->dev.shareMinIdle = 0;
   s->dev.sharePeriodMask = 0;
@@ -802,10 +844,6 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     s->dev.sharePeriodMask = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_PERIOD];
     s->dev.shareFlags |= (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 1u;
   }
-#if defined(VKRT_EXP) && VKRT_EXP == 10
-  if(const char* e = getenv("VKRT_STACK_CAP_WORDS"))  // experiment #99: a smaller stack frees LDS for a sixth wave per SIMD (overflows are counted as faults)
-    s->dev.stackCap = (uint32_t)atoi(e);
-#endif
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
   if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)
     return fail(VKRT_ERR_UNSUPPORTED, "BVH depth %u needs a %zu-byte LDS stack per workgroup (limit 64 KiB)", s->info.max_depth,
@@ -844,8 +882,18 @@ uint32_t vkrt_shard_rows(const vkrt_shard* sh)
 int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts,
                    const vkrt_shard* shard, float* image, void* hip_stream)
 {
+  return vkrt_pathtrace_frames(s, pc, cam, opts, shard, image, 1u, hip_stream);
+}
+
+int vkrt_pathtrace_frames(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* cam, const vkrt_trace_opts* opts,
+                          const vkrt_shard* shard, float* image, uint32_t n_frames, void* hip_stream)
+{
   if(!s || !pc || !cam || !shard)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(n_frames == 0u)
+    return VKRT_OK;
+  if(n_frames > 65536u || (int64_t)pc->frame + (int64_t)n_frames > 0x7fffffffll)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "n_frames %u out of range", n_frames);
   if(!image && vkrt_shard_rows(shard) != 0u)  // (a shard without rows -- more ranks than strips -- has no image to pass)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL image");
   if(!s->built)
@@ -897,12 +945,15 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   {
     if(P.fullW > 65535u || P.localRows > 65535u || pc->samples > 65535)
       return fail(VKRT_ERR_UNSUPPORTED, "wavefront mode packs pixel coordinates / sample index in 16 bits");
-    if((rc = ensureWorkingSet(s, P.tileCount * 64u, stream)) != VKRT_OK)
+    const uint32_t seedStep = (P.flags & VKRT_TRACE_SAME_SEED_EVERY_FRAME) ? 0u : 1u;
+    if((rc = ensureWorkingSet(s, P.tileCount * 64u, framesInFlight(s, (int)n_frames), stream)) != VKRT_OK)
+      return rc;
+    if((rc = ensureEventPool(s, (int)std::min<uint32_t>(n_frames, VKRT_FRAMES_PER_BATCH))) != VKRT_OK)
       return rc;
     WfTiming* timing = nullptr;
     if(P.flags & VKRT_TRACE_TIME_KERNELS)
     {
-      const size_t wantEv = (size_t)2 * (2 * (size_t)pc->samples * pc->depth);
+      const size_t wantEv = (size_t)2 * (2 * (size_t)pc->samples * pc->depth) * std::min<uint32_t>(n_frames, 8u);
       while(s->wfEvents.size() < wantEv && s->wfEvents.size() < 8192)
       {
         hipEvent_t e;
@@ -918,7 +969,14 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
     WfOptions wo;
     wo.subframes = s->opt[VKRT_OPT_WF_SUBFRAMES];
     wo.travBlock = (s->dev.watertight || s->dev.dissolve) ? 64 : s->opt[VKRT_OPT_WF_TRAV_BLOCK];  // (the non-default triangle modes exist for the default workgroup only)
-    HIP_TRY(vkrt_launch_wavefront(P, s->wf, wo, count, stream, timing, &s->wfAsync));
+    wo.inFlight = framesInFlight(s, (int)n_frames);
+    for(uint32_t first = 0; first < n_frames; first += VKRT_FRAMES_PER_BATCH)
+    {
+      TraceParams Pb = P;
+      Pb.pc.frame = P.pc.frame + (int)first;
+      Pb.seed = P.seed + first * seedStep;
+      HIP_TRY(vkrt_launch_wavefront(Pb, s->wf, wo, (int)std::min<uint32_t>(VKRT_FRAMES_PER_BATCH, n_frames - first), seedStep, count, stream, timing, &s->wfAsync));
+    }
     HIP_TRY(hipEventRecord(s->evStop, stream));
     s->timed = true;
     return VKRT_OK;
@@ -931,9 +989,15 @@ int vkrt_pathtrace(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniform
   const uint64_t wantBlocks = (tiles * 64 + 255) / 256;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wantBlocks, (uint64_t)s->cuCount * perCU));
 
-  HIP_TRY(hipMemsetAsync(s->workCounter, 0, sizeof(unsigned int), stream));
   HIP_TRY(hipEventRecord(s->evStart, stream));
-  HIP_TRY(vkrt_launch_pathtrace(P, grid, count, stream));
+  for(uint32_t k = 0; k < n_frames; k++)  // the megakernel renders the frames of a call one after another
+  {
+    TraceParams Pk = P;
+    Pk.pc.frame = P.pc.frame + (int)k;
+    Pk.seed = P.seed + ((P.flags & VKRT_TRACE_SAME_SEED_EVERY_FRAME) ? 0u : k);
+    HIP_TRY(hipMemsetAsync(s->workCounter, 0, sizeof(unsigned int), stream));
+    HIP_TRY(vkrt_launch_pathtrace(Pk, grid, count, stream));
+  }
   HIP_TRY(hipEventRecord(s->evStop, stream));
   s->timed = true;
   s->wfTimed = false;
@@ -1077,7 +1141,7 @@ int hybridImpl(vkrt_scene* s, const PushConstantRay* pc, const GlobalUniforms* c
   const bool giOnStreams = s->wavefront && pc->useGI == 1 && P.fullW <= 65535u && P.localRows <= 65535u;
   if(giOnStreams)
   {
-    if((rc = ensureWorkingSet(s, P.tileCount * 64u, stream)) != VKRT_OK)
+    if((rc = ensureWorkingSet(s, P.tileCount * 64u, 1, stream)) != VKRT_OK)
       return rc;
     P.tileFirst = 0;
     HIP_TRY(vkrt_launch_hybrid(P, g->color, g->position, g->normal, g->roughMetal, accum, nrd ? &np : nullptr, vkrt_wf_hybrid_tmp(s->wf), stream));
@@ -1229,16 +1293,42 @@ int vkrt_debug_check_accel(vkrt_scene* s, vkrt_accel_check* out)
   std::vector<uint8_t> reached(N, 0);
   struct Bound { float lo[3], hi[3]; };
   std::vector<Bound> chain;  // boxes of the slots on the path from the root
+  // slots per triangle id: a triangle with one slot must lie inside every box above that slot (its vertices do: convexity); the slots
+  // of a pre-split triangle (VKRT_OPT_SPLIT_BUDGET) are checked together at the end: `reach[slot]` = intersection of the chain
+  auto gidOf = [&](uint32_t slot) { uint32_t g; memcpy(&g, &tris[(size_t)slot * 12 + 9], 4); return g & 0x7fffffffu; };
+  auto vertexOf = [&](uint32_t slot, int v, float p[3]) {
+    const float* t = &tris[(size_t)slot * 12];  // (v0, e1, e2) or, watertight, (p0, p1, p2)
+    for(int k = 0; k < 3; k++)
+      p[k] = v == 0 ? t[k] : (s->dev.watertight ? t[3 * v + k] : (v == 1 ? t[k] + t[3 + k] : t[k] + t[6 + k]));
+  };
+  const uint32_t gidCount = s->info.triangle_count;
+  std::vector<uint32_t> slotsOfGid(gidCount, 0u);
+  for(uint32_t k = 0; k < T; k++)
+  {
+    const uint32_t g = gidOf(k);
+    if(g < gidCount) slotsOfGid[g]++; else out->bad_references++;
+  }
+  std::vector<Bound> reach(T);
+  for(Bound& b : reach)
+    for(int k = 0; k < 3; k++) { b.lo[k] = -INFINITY; b.hi[k] = INFINITY; }
   auto checkTriangle = [&](uint32_t slot) {
     out->triangles_referenced++;
     if(slot >= T) { out->bad_references++; return; }
-    if(seen[slot]++) out->triangles_repeated++;
-    const float* t = &tris[(size_t)slot * 12];  // v0, e1, e2
+    if(seen[slot]++) { out->triangles_repeated++; return; }
+    const uint32_t g = gidOf(slot);
+    const bool single = g < gidCount && slotsOfGid[g] == 1u;
+    for(const Bound& b : chain)
+      for(int k = 0; k < 3; k++)
+      {
+        reach[slot].lo[k] = std::max(reach[slot].lo[k], b.lo[k]);
+        reach[slot].hi[k] = std::min(reach[slot].hi[k], b.hi[k]);
+      }
+    if(!single)
+      return;
     for(int v = 0; v < 3; v++)
     {
       float p[3];
-      for(int k = 0; k < 3; k++)
-        p[k] = v == 0 ? t[k] : (s->dev.watertight ? t[3 * v + k] : (v == 1 ? t[k] + t[3 + k] : t[k] + t[6 + k]));
+      vertexOf(slot, v, p);
       for(const Bound& b : chain)
         for(int k = 0; k < 3; k++)
           if(!(p[k] >= b.lo[k] && p[k] <= b.hi[k])) { out->box_violations++; break; }
@@ -1343,6 +1433,49 @@ int vkrt_debug_check_accel(vkrt_scene* s, vkrt_accel_check* out)
   }
   for(uint32_t t = 0; t < T; t++)
     if(!seen[t]) out->triangles_missing++;
+  // pre-split triangles: every lattice point of the triangle must be reachable through at least one of its slots
+  {
+    std::vector<uint32_t> first(gidCount + 1, 0u), fill(gidCount, 0u), bySlot(T);
+    for(uint32_t g = 0; g < gidCount; g++) first[g + 1] = first[g] + slotsOfGid[g];
+    for(uint32_t k = 0; k < T; k++)
+    {
+      const uint32_t g = gidOf(k);
+      if(g < gidCount) bySlot[first[g] + fill[g]++] = k;
+    }
+    for(uint32_t g = 0; g < gidCount; g++)
+    {
+      if(slotsOfGid[g] == 0u) { out->triangles_uncovered++; continue; }  // an instanced triangle the tree does not hold at all
+      if(slotsOfGid[g] == 1u) continue;
+      out->triangles_split++;
+      const uint32_t s0 = bySlot[first[g]];
+      float v[3][3];
+      for(int c = 0; c < 3; c++) vertexOf(s0, c, v[c]);
+      bool covered = true;
+      const int n = 8;  // lattice: barycentric (i, j, n - i - j) / n
+      for(int i = 0; i <= n && covered; i++)
+        for(int j = 0; i + j <= n && covered; j++)
+        {
+          double p[3];
+          for(int k = 0; k < 3; k++) p[k] = ((double)v[0][k] * (n - i - j) + (double)v[1][k] * i + (double)v[2][k] * j) / n;
+          bool inSome = false;
+          for(uint32_t q = first[g]; q < first[g + 1] && !inSome; q++)
+          {
+            if(!seen[bySlot[q]]) continue;
+            const Bound& b = reach[bySlot[q]];
+            bool in = true;
+            // (the lattice point is rounded from double; a piece's box is padded by 8 ulp of the coordinates: allow as much)
+            for(int k = 0; k < 3; k++)
+            {
+              const double tol = 1e-6 * std::max(1.0, std::fabs(p[k]));
+              in = in && p[k] >= (double)b.lo[k] - tol && p[k] <= (double)b.hi[k] + tol;
+            }
+            inSome = in;
+          }
+          covered = inSome;
+        }
+      if(!covered) out->triangles_uncovered++;
+    }
+  }
   return VKRT_OK;
 }
 

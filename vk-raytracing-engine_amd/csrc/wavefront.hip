@@ -73,24 +73,17 @@ VKRT_DEV float4* plane(const WfBuffers& B, int parity, int type, int k)
 }
 VKRT_DEV unsigned* countOf(const WfBuffers& B, int parity, int type) { return &B.ctrl[parity * 4 + type]; }
 
-// Stream records are written once and read once: the read is their last use, so it is a non-temporal load (the `nt` policy bit) and
-// the record does not displace tree nodes and triangles from L2 / Infinity Cache on its way out: +1.5 % ray rate on the bench scene,
-// +1.8 % on the Sponza-like one.  The stores stay ordinary -- the next kernel reads the records from the caches; written
-// non-temporally they come back from HBM and the frame is 4.5 % slower (profiles/r03_experiments.md #103; EXP 15 / 17 keep that variant).
+// Stream records are written by one kernel and consumed by the next one or two (the traversal kernel reads the ray planes, the shade
+// kernel the rest; the direction and seed planes are read by both): no later round reads them again, so they are fetched with non-temporal
+// loads (the `nt` policy bit) and do not displace tree nodes and triangles from L2 / Infinity Cache on their way out: +1.5 % ray rate on
+// the bench scene, +1.8 % on the Sponza-like one.  The stores stay ordinary -- the next kernel reads the records from the caches; written
+// non-temporally they come back from HBM and the frame is 4.5 % slower (profiles/r03_experiments.md #103).
 VKRT_DEV float4 wfLoad(const float4* p)
 {
   const vkrt_v4f v = __builtin_nontemporal_load((const vkrt_v4f*)p);
   return make_float4(v.x, v.y, v.z, v.w);
 }
-#if defined(VKRT_EXP) && (VKRT_EXP == 15 || VKRT_EXP == 17)
-VKRT_DEV void wfStore(float4* p, float4 v)
-{
-  const vkrt_v4f w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, (vkrt_v4f*)p);
-}
-#else
 VKRT_DEV void wfStore(float4* p, float4 v) { *p = v; }
-#endif
 
 VKRT_DEV unsigned packFlags(const LaneState& L)
 {
@@ -171,11 +164,6 @@ VKRT_DEV unsigned claimSlots(const WfBuffers& B, int parity, int to, unsigned la
       tot += c;
     }
     w[nw] = tot ? atomicAdd(countOf(B, parity, (int)threadIdx.x), tot) : 0u;
-#if defined(VKRT_EXP) && VKRT_EXP == 3
-    // experiment #87: is the shade stage bound by these returning atomics on three words of one line?  Double them (a dummy
-    // counter on a line of its own per stream type) and see whether the kernel gets slower.
-    if(tot) w[nw] += 0u * atomicAdd(&B.ctrl[16 + 16 * threadIdx.x + (parity & 1)], tot);
-#endif
   }
   __syncthreads();
   if(to < 0)
@@ -256,11 +244,7 @@ VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int ki
 // ---- traversal: one thread per queued ray, workgroups homogeneous in ray kind -----------------------------------
 template <bool COUNT, bool WIDE, int TB, int TM = 0>
 __global__ __launch_bounds__(TB)
-#if defined(VKRT_EXP) && VKRT_EXP == 10
-__attribute__((amdgpu_waves_per_eu(WIDE && TB == 64 ? (TM != 0 ? 5 : 6) : 1)))  // experiment #99: six waves per SIMD (80 VGPRs + 16 B of scratch)
-#else
 __attribute__((amdgpu_waves_per_eu(TM != 0 && WIDE && TB == 64 ? 5 : 1)))
-#endif
 void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
 {
   extern __shared__ int lds_stack[];
@@ -308,17 +292,10 @@ void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
   {
     // the whole wave walks together: lanes past the end of the stream have no ray of their own but help
     uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
-    vkrt_lds_float4* topLds = nullptr;
-#if VKRT_TOP_NODES > 0
-    __shared__ float4 topNodes[VKRT_TOP_NODES * VKRT_WNODE_QUADS];
-    for(unsigned k = threadIdx.x; k < VKRT_TOP_NODES * VKRT_WNODE_QUADS; k += 64u) topNodes[k] = P.sc.nodes[k];
-    shareSync();
-    topLds = (vkrt_lds_float4*)topNodes;
-#endif
     if(anyHit)
-      traverse_wide8_share<COUNT, true, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed, topLds);
+      traverse_wide8_share<COUNT, true, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
     else
-      traverse_wide8_share<COUNT, false, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed, topLds);
+      traverse_wide8_share<COUNT, false, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
     if(valid)
       storeHit(P, B, par, kind, qi, hit);
   }
@@ -507,12 +484,6 @@ VKRT_DEV void shadeRound(const TraceParams& P, const WfBuffers& B, const HybridG
   else if((blk -= nP) < nS)
     shadeShadowBlock<HYBRID>(P, B, G, par, cS, blk);
 }
-#if defined(VKRT_EXP) && VKRT_EXP == 4
-__attribute__((amdgpu_waves_per_eu(4)))  // experiment #88: the shade kernel at four waves per SIMD (<= 128 VGPRs) instead of three
-#endif
-#if defined(VKRT_EXP) && VKRT_EXP == 5
-__attribute__((amdgpu_waves_per_eu(5)))  // experiment #93: the traversal kernel's register footprint (96 VGPRs, spills to scratch): interchangeable wave slots
-#endif
 __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
 {
   const HybridGi none{};
@@ -595,19 +566,43 @@ __global__ __launch_bounds__(WF_BLOCK) void k_hy_gi_init(const TraceParams P, co
     storeClosest(B, 0, slot, L);
 }
 
-// ---- host side ------------------------------------------------------------------------------------------------------
-size_t vkrt_wf_state_bytes(uint32_t pathCapacity)
+// ---- frames in flight: ordered blend of a staged frame (raytrace.rgen:136-145) ---------------------------------------------------
+// One thread per pixel of the lane's tiles (tile-major, as k_wf_init): image = mix(image, staged, 1 / (frame + 1)), or the plain
+// store of frame 0.  Launched at the end of a frame on the frame's own lane, behind the blend of the frame before it.
+__global__ __launch_bounds__(WF_BLOCK) void k_wf_blend(const TraceParams P, const float4* stage)
 {
-  return (size_t)pathCapacity * 2 * WF_TYPES * WF_PLANES * sizeof(float4) + 256 * VKRT_WF_MAX_SUBFRAMES;
+  const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+  if(w >= P.tileCount * 64u)
+    return;
+  const unsigned tile = P.tileFirst + (w >> 6), inTile = w & 63u;
+  const uint32_t x = (tile % P.tilesX) * 8u + (inTile & 7u);
+  const uint32_t lrow = (tile / P.tilesX) * 8u + (inTile >> 3);
+  if(x < P.fullW && lrow < P.localRows && globalRow(P, lrow) < P.fullH)
+  {
+    const size_t p = (size_t)lrow * P.fullW + x;
+    blendPixel((float4*)P.image + p, stage[p], P.pc.frame);
+  }
 }
 
-void vkrt_wf_carve(void* base, uint32_t pathCapacity, WfBuffers* B)
+// ---- host side ------------------------------------------------------------------------------------------------------
+#define WF_CTRL_BYTES (256 * VKRT_WF_MAX_LANES)  // 64 count words per lane
+size_t vkrt_wf_state_bytes(uint32_t pathCapacity, int groups)
 {
+  const size_t g = (size_t)std::max(groups, 1);
+  return g * pathCapacity * 2 * WF_TYPES * WF_PLANES * sizeof(float4) + (g > 1 ? g * pathCapacity * sizeof(float4) : 0) + WF_CTRL_BYTES;
+}
+
+void vkrt_wf_carve(void* base, uint32_t pathCapacity, int groups, WfBuffers* B)
+{
+  const size_t g = (size_t)std::max(groups, 1);
   char* p = (char*)base;
-  B->ctrl = (unsigned*)p;  // 256 bytes of counts per sub-frame
-  p += 256 * VKRT_WF_MAX_SUBFRAMES;
+  B->ctrl = (unsigned*)p;
+  p += WF_CTRL_BYTES;
   B->planes = (float4*)p;
+  p += g * pathCapacity * 2 * WF_TYPES * WF_PLANES * sizeof(float4);
+  B->stage = g > 1 ? (float4*)p : nullptr;
   B->capacity = pathCapacity;
+  B->groups = (uint32_t)g;
 }
 
 // One traversal launch: the instantiation for (instrumented?, node layout, workgroup size, triangle mode).  The non-default triangle
@@ -618,12 +613,6 @@ static void launchTraverse(const TraceParams& P, const WfBuffers& B, int r, unsi
   const bool wide = P.sc.layout == 1u;
   const int tm = (P.sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (P.sc.dissolve ? VKRT_TM_DISSOLVE : 0);
   const dim3 tb(travBlock);
-#if defined(VKRT_EXP) && VKRT_EXP == 11
-  // experiment #100: pad the traversal workgroup's LDS so that fewer of them fit a CU and the shade waves of the other sub-frames
-  // (142 VGPRs) find register room beside them
-  static const size_t ldsPad = getenv("VKRT_TRAV_LDS_PAD") ? (size_t)atoi(getenv("VKRT_TRAV_LDS_PAD")) : 0;
-  tlds += ldsPad;
-#endif
 #define VKRT_TRAV_LAUNCH(C, W, TB, TM) hipLaunchKernelGGL((k_wf_traverse<C, W, TB, TM>), tg, tb, tlds, stream, P, B, r)
 #define VKRT_TRAV_MODES(TB, TM)                                                                                                        \
   do {                                                                                                                                 \
@@ -682,52 +671,170 @@ static void subframeRound(const TraceParams& P, const WfBuffers& B, int r, unsig
   hipLaunchKernelGGL(k_wf_shade, dim3((work + WF_BLOCK - 1) / WF_BLOCK + 3), dim3(WF_BLOCK), 0, stream, P, B, r);
 }
 
-hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, bool count, hipStream_t stream, WfTiming* timing,
-                                 const WfAsync* async)
+// parameters of frame k of a call (progressive frames of an unchanged camera: main.cpp:503-508, hello_vulkan.cpp:1501-1521)
+static TraceParams frameParams(const TraceParams& P, int k, uint32_t seedStep)
 {
-  const int want = std::max(1, std::min(VKRT_WF_MAX_SUBFRAMES, opt.subframes));
+  TraceParams Q = P;
+  Q.pc.frame = P.pc.frame + k;
+  Q.seed = P.seed + (uint32_t)k * seedStep;
+  return Q;
+}
+
+// frames a call of `frames` frames keeps in flight when the option allows `want`: as many rounds of `want` as the call needs, the frames
+// dealt evenly over them (4 frames, want 3 -> two rounds of 2, not 3 + 1: measured 30.8 against 31.5 ms per frame on a 4K / 8 shard)
+static int balancedInFlight(int frames, int want)
+{
+  want = std::max(1, std::min(want, frames));
+  const int turns = (frames + want - 1) / want;
+  return (frames + turns - 1) / turns;
+}
+
+hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, int frames, uint32_t seedStep, bool count,
+                                 hipStream_t stream, WfTiming* timing, const WfAsync* async)
+{
   const unsigned travBlock = opt.travBlock == 256 ? 256u : opt.travBlock == 128 ? 128u : 64u;
-  // per-kernel timing wants the kernels one after another; tiny frames are not worth splitting
-  int n = (timing || !async) ? 1 : std::min(want, async->count);
-  n = (int)std::min<uint32_t>((uint32_t)std::max(n, 1), std::max(1u, P.tileCount / 256u));
   const int rounds = subframeRounds(P);
+  frames = std::max(frames, 1);
+  // Lanes: F frame groups x S tile ranges.  Frames in flight keep every launch at full size, sub-frames cut it into S pieces -- and
+  // what overlaps well on this device is few, large launches (profiles/r04_experiments.md #110: two or three full-size lanes reach
+  // 0.96-0.97 of linear on a 4K / 8 shard, three third-size lanes 0.90, four quarter-size lanes 0.77): a call with several frames
+  // runs them in flight, one lane each; a single frame is split into sub-frames.  Per-kernel timing wants the kernels one after
+  // another; tiny frames are not worth splitting.
+  int F = (timing || !async || rounds == 0) ? 1 : std::min(balancedInFlight(frames, opt.inFlight), (int)B.groups);
+  F = std::max(1, std::min(F, async ? std::min(VKRT_WF_MAX_LANES, async->count) : 1));
+  int S = (timing || !async || F > 1) ? 1 : std::max(1, std::min(std::min(VKRT_WF_MAX_LANES, opt.subframes), async->count));
+  S = (int)std::min<uint32_t>((uint32_t)S, std::max(1u, P.tileCount / 256u));
+  const int L = S * F;
   hipError_t e;
-  if(n <= 1)
+  if(L <= 1)
   {
-    TraceParams Q = P;
-    Q.tileFirst = 0;
-    if((e = subframeBegin(Q, B, stream)) != hipSuccess) return e;
     if(timing)
       timing->used = 0;
-    for(int r = 0; r < rounds; r++) subframeRound(Q, B, r, travBlock, count, stream, timing);
+    for(int k = 0; k < frames; k++)
+    {
+      TraceParams Q = frameParams(P, k, seedStep);
+      Q.tileFirst = 0;
+      if((e = subframeBegin(Q, B, stream)) != hipSuccess) return e;
+      for(int r = 0; r < rounds; r++) subframeRound(Q, B, r, travBlock, count, stream, timing);
+    }
     return hipGetLastError();
   }
+  // ---- several lanes ------------------------------------------------------------------------------------------------------
+  // lane q = g * S + j: tile range j of the frames of group g (frames g, g + F, g + 2 F, ...)
+  const bool staged = F > 1;
+  if(staged && vkrt_wf_pool_events(frames, S) > async->poolSize)
+    return hipErrorInvalidValue;  // (the caller sizes the pool: vkrt_api.cpp)
+  hipStream_t laneStream[VKRT_WF_MAX_LANES];
+  uint32_t tile0[VKRT_WF_MAX_LANES], tileN[VKRT_WF_MAX_LANES];
+  WfBuffers Bq[VKRT_WF_MAX_LANES];
+  const size_t groupQuads = (size_t)2 * WF_TYPES * WF_PLANES * B.capacity;
+  for(int q = 0; q < L; q++)
+  {
+    const int g = q / S, j = q % S;
+    tile0[q] = (uint32_t)((uint64_t)P.tileCount * j / S);
+    tileN[q] = (uint32_t)((uint64_t)P.tileCount * (j + 1) / S) - tile0[q];
+    Bq[q].ctrl = B.ctrl + 64 * q;
+    Bq[q].planes = B.planes + (size_t)g * groupQuads + (size_t)2 * WF_TYPES * WF_PLANES * ((size_t)tile0[q] * 64u);
+    Bq[q].stage = staged ? B.stage + (size_t)g * B.capacity : nullptr;
+    Bq[q].capacity = tileN[q] * 64u;
+    Bq[q].groups = 1;
+    laneStream[q] = async->streams[q];
+  }
+  // fork: every lane starts behind what the caller enqueued before this call; whatever happens afterwards, the lanes that were
+  // started are joined to the caller's stream again before the function returns (nothing of a failed call runs on unordered)
+  int forked = 0;
+  auto joinLanes = [&]() {
+    hipError_t first = hipSuccess;
+    for(int q = 0; q < forked; q++)
+    {
+      hipError_t x = hipEventRecord(async->join[q], laneStream[q]);
+      if(x == hipSuccess) x = hipStreamWaitEvent(stream, async->join[q], 0);
+      if(x != hipSuccess)
+      {
+        (void)hipStreamSynchronize(laneStream[q]);
+        if(first == hipSuccess) first = x;
+      }
+    }
+    return first;
+  };
   if((e = hipEventRecord(async->fork, stream)) != hipSuccess) return e;
-  TraceParams Q[VKRT_WF_MAX_SUBFRAMES];
-  WfBuffers Bj[VKRT_WF_MAX_SUBFRAMES];
-  for(int j = 0; j < n; j++)
+  for(int q = 0; q < L; q++)
   {
-    const uint32_t t0 = (uint32_t)((uint64_t)P.tileCount * j / n), t1 = (uint32_t)((uint64_t)P.tileCount * (j + 1) / n);
-    Q[j] = P;
-    Q[j].tileFirst = t0;
-    Q[j].tileCount = t1 - t0;
-    Bj[j].ctrl = B.ctrl + 64 * j;
-    Bj[j].planes = B.planes + (size_t)2 * WF_TYPES * WF_PLANES * ((size_t)t0 * 64u);
-    Bj[j].capacity = Q[j].tileCount * 64u;
-    if((e = hipStreamWaitEvent(async->streams[j], async->fork, 0)) != hipSuccess) return e;
-    if((e = subframeBegin(Q[j], Bj[j], async->streams[j])) != hipSuccess) return e;
+    if((e = hipStreamWaitEvent(laneStream[q], async->fork, 0)) != hipSuccess)
+    {
+      (void)joinLanes();
+      return e;
+    }
+    forked = q + 1;
   }
-  // The rounds are enqueued INTERLEAVED -- round r of every sub-frame before round r + 1 of any: enqueueing one sub-frame's ~290
-  // launches after the other's makes stream j start j x ~1.2 ms of host time late, which a 33-ms shard of a 4K frame feels
-  // (N = 8 rehearsal 0.891 -> 0.905, profiles/r03_experiments.md #106) and a whole 1080p frame does not.
-  for(int r = 0; r < rounds; r++)
-    for(int j = 0; j < n; j++) subframeRound(Q[j], Bj[j], r, travBlock, count, async->streams[j], nullptr);
-  for(int j = 0; j < n; j++)
+  // Items of a lane's m-th frame: 0 = begin, 1..rounds = the rounds, rounds + 1 = ordered blend (frames in flight only).  The host
+  // deals the items of all lanes round-robin -- item i of every lane before item i + 1 of any: enqueueing one lane's hundreds of
+  // launches after the other's makes the later lanes start milliseconds late (profiles/r03_experiments.md #106).  The blend of
+  // frame k waits for the blend of frame k - 1 (same tiles, another lane) through an event of the pool, one per (frame, tile
+  // range), so no record call ever replaces one that still has a wait to come; a lane whose blend would wait for a record the
+  // host has not made yet is skipped for a turn (hipStreamWaitEvent refers to the record calls made BEFORE it).
+  const int items = rounds + 1 + (staged ? 1 : 0);
+  hipEvent_t* evBlend = async->pool;  // [frame k][tile range j]
+  int laneFrames[VKRT_WF_MAX_LANES], cursor[VKRT_WF_MAX_LANES];
+  std::vector<char> blendRecorded(staged ? (size_t)frames * S : 0, 0);
+  int remaining = 0;
+  for(int q = 0; q < L; q++)
   {
-    if((e = hipEventRecord(async->join[j], async->streams[j])) != hipSuccess) return e;
-    if((e = hipStreamWaitEvent(stream, async->join[j], 0)) != hipSuccess) return e;
+    laneFrames[q] = (frames - q / S + F - 1) / F;
+    cursor[q] = 0;
+    remaining += laneFrames[q] * items;
   }
-  return hipGetLastError();
+  e = hipSuccess;
+  while(remaining > 0 && e == hipSuccess)
+  {
+    bool progressed = false;
+    for(int q = 0; q < L && e == hipSuccess; q++)
+    {
+      if(cursor[q] >= laneFrames[q] * items)
+        continue;
+      const int g = q / S, j = q % S, m = cursor[q] / items, it = cursor[q] % items, k = g + m * F;
+      TraceParams Q = frameParams(P, k, seedStep);
+      Q.tileFirst = tile0[q];
+      Q.tileCount = tileN[q];
+      if(staged)
+      {
+        Q.image = (float*)Bq[q].stage;
+        Q.flags |= VKRT_FLAG_STORE_STAGED;
+      }
+      hipStream_t st = laneStream[q];
+      if(it == 0)
+      {
+        if((e = subframeBegin(Q, Bq[q], st)) != hipSuccess) break;
+      }
+      else if(it <= rounds)
+        subframeRound(Q, Bq[q], it - 1, travBlock, count, st, nullptr);
+      else
+      {
+        // the frame's pixels are staged: blend them into the image behind the blend of frame k - 1
+        if(k > 0)
+        {
+          if(!blendRecorded[(size_t)(k - 1) * S + j])
+            continue;
+          if((e = hipStreamWaitEvent(st, evBlend[(k - 1) * S + j], 0)) != hipSuccess) break;
+        }
+        TraceParams R = Q;
+        R.image = P.image;
+        const unsigned work = R.tileCount * 64u;
+        hipLaunchKernelGGL(k_wf_blend, dim3((work + WF_BLOCK - 1) / WF_BLOCK), dim3(WF_BLOCK), 0, st, R, (const float4*)Bq[q].stage);
+        if(k + 1 < frames && (e = hipEventRecord(evBlend[k * S + j], st)) != hipSuccess) break;
+        blendRecorded[(size_t)k * S + j] = 1;
+      }
+      cursor[q]++;
+      remaining--;
+      progressed = true;
+    }
+    if(!progressed && e == hipSuccess)
+      e = hipErrorUnknown;  // (cannot happen: the blends follow frame order)
+  }
+  const hipError_t ej = joinLanes();
+  if(e == hipSuccess) e = ej;
+  if(e == hipSuccess) e = hipGetLastError();
+  return e;
 }
 
 // ---- hybrid GI -------------------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -66,9 +67,13 @@ void HelloVkrt::createTopLevelAsGltf()
   if(!m_scene || !m_blasRequested)
     throw std::runtime_error("createTopLevelAsGltf before createBottomLevelASGltf");
   // per-handle options the acceleration-structure build consumes (include/vkrt.h): the triangle test, the any-hit stage
-  check(vkrt_scene_set_option(m_scene, VKRT_OPT_WATERTIGHT, m_watertight ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_WATERTIGHT)");
-  check(vkrt_scene_set_option(m_scene, VKRT_OPT_ANYHIT_DISSOLVE, m_anyHitDissolve ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_ANYHIT_DISSOLVE)");
-  check(vkrt_scene_set_option(m_scene, VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, m_skipDeadShadowRays ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_SKIP_DEAD_SHADOW_RAYS)");
+  // (only what was specified: an unspecified option keeps the value vkrt_scene_create read from the environment)
+  if(m_watertight >= 0)
+    check(vkrt_scene_set_option(m_scene, VKRT_OPT_WATERTIGHT, m_watertight ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_WATERTIGHT)");
+  if(m_anyHitDissolve >= 0)
+    check(vkrt_scene_set_option(m_scene, VKRT_OPT_ANYHIT_DISSOLVE, m_anyHitDissolve ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_ANYHIT_DISSOLVE)");
+  if(m_skipDeadShadowRays >= 0)
+    check(vkrt_scene_set_option(m_scene, VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, m_skipDeadShadowRays ? 1 : 0), "vkrt_scene_set_option(VKRT_OPT_SKIP_DEAD_SHADOW_RAYS)");
   check(vkrt_accel_build(m_scene, m_buildFlags, nullptr), "vkrt_accel_build");
 }
 
@@ -126,6 +131,27 @@ void HelloVkrt::pathtrace(const float clearColor[4])
   const vkrt_trace_opts opts{m_seed, m_traceFlags};
   const vkrt_shard shard = launchShard();
   check(vkrt_pathtrace(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, m_offscreenColor, nullptr), "vkrt_pathtrace");
+}
+
+void HelloVkrt::pathtraceFrames(const float clearColor[4], int n, bool seedPerFrame)
+{
+  if(n <= 0)
+    return;
+  if(m_stopAtMaxFrames)  // hello_vulkan.cpp:1426: frames >= m_maxFrames are not rendered
+  {
+    if(m_pcRay.frame >= m_maxFrames)
+      return;
+    n = std::min(n, m_maxFrames - m_pcRay.frame);
+  }
+  if(!m_scene || !m_offscreenColor)
+    throw std::runtime_error("pathtraceFrames before scene/offscreen image creation");
+  for(int k = 0; k < 4; k++) m_pcRay.clearColor[k] = clearColor[k];
+  const vkrt_trace_opts opts{m_seed, m_traceFlags | (seedPerFrame ? 0u : (uint32_t)VKRT_TRACE_SAME_SEED_EVERY_FRAME)};
+  const vkrt_shard shard = launchShard();
+  check(vkrt_pathtrace_frames(m_scene, &m_pcRay, &m_hostUBO, &opts, &shard, m_offscreenColor, (uint32_t)n, nullptr), "vkrt_pathtrace_frames");
+  m_pcRay.frame += n - 1;
+  if(seedPerFrame)
+    m_seed += (uint32_t)(n - 1);
 }
 
 // the launch geometry of this rank: the whole image, or its strips of the full-size launch (setShard)
@@ -254,9 +280,12 @@ AppConfig parseConfig(const std::string& text)
   c.useShadows = j["useShadows"].boolean(c.useShadows);
   c.useAO = j["useAO"].boolean(c.useAO);
   c.useGI = j["useGI"].boolean(c.useGI);
-  c.watertight = j["watertight"].boolean(c.watertight);
-  c.anyHitDissolve = j["anyHitDissolve"].boolean(c.anyHitDissolve);
-  c.skipDeadShadowRays = j["skipDeadShadowRays"].boolean(c.skipDeadShadowRays);
+  if(j.has("watertight")) c.watertight = j["watertight"].boolean(false) ? 1 : 0;
+  if(j.has("anyHitDissolve")) c.anyHitDissolve = j["anyHitDissolve"].boolean(false) ? 1 : 0;
+  if(j.has("skipDeadShadowRays")) c.skipDeadShadowRays = j["skipDeadShadowRays"].boolean(false) ? 1 : 0;
+  c.framesPerCall = j["framesPerCall"].integer(c.framesPerCall);
+  if(c.framesPerCall < 1)
+    throw std::runtime_error("config.json: \"framesPerCall\" must be >= 1");
   c.output = j["output"].string("");
   if(j.has("clearColor"))
     for(int k = 0; k < 4; k++) c.clearColor[k] = (float)j["clearColor"][(size_t)k].number(1.0);

@@ -46,6 +46,11 @@ public:
   void resetFrame();                                      // :1501-1504
   void updateFrame();                                     // :1506-1521
   void pathtrace(const float clearColor[4]);              // :1423-1448
+  // n iterations of the frame loop with the camera at rest (main.cpp:503-508: updateFrame() -> pathtrace(), n times) as ONE library
+  // call (vkrt_pathtrace_frames): call it after updateFrame() like pathtrace(); it renders frames m_pcRay.frame .. + n - 1 with seeds
+  // m_seed .. + n - 1 (m_seed for all of them when seedPerFrame is false) and leaves m_pcRay.frame / m_seed at the LAST frame's
+  // values, as n - 1 further updateFrame() calls would.  m_stopAtMaxFrames cuts the count like the reference's early return does.
+  void pathtraceFrames(const float clearColor[4], int n, bool seedPerFrame = true);
   // hybrid mode (rtMode == 0): main.cpp:510-561 = rasterizeGltf -> raytraceRasterizedScene -> drawPost
   void rasterizeGltf(const float clearColor[4]);          // :583-615 (ray-cast G-buffer: no raster path from HIP)
   void raytraceRasterizedScene();                         // :1450-1473
@@ -68,18 +73,20 @@ public:
 
   // public state, as in the reference class
   PushConstantRay m_pcRay{{1, 1, 1, 1}, -1, 0, 1, 3, 1, 1, 0};  // frame = -1 until the first updateFrame
-  int m_maxFrames{10};            // hello_vulkan.h:156
-  bool m_stopAtMaxFrames{false};  // hello_vulkan.h:157
+  bool m_stopAtMaxFrames{false};  // hello_vulkan.h:156
+  int m_maxFrames{1};             // hello_vulkan.h:157
   CameraManipulator CameraManip;  // the nvh global of the reference
   GlobalUniforms m_hostUBO{};
   GltfScene m_gltfScene;
   struct { int width = 1280, height = 720; } m_size;
   uint32_t m_seed = 0;            // replaces int(clockARB()) (raytrace.rgen:27); advanced every frame
   uint32_t m_buildFlags = VKRT_BUILD_DEFAULT;
-  // library options without a counterpart in the reference class (include/vkrt.h vkrt_option); applied by createTopLevelAsGltf
-  bool m_watertight = false;          // VKRT_OPT_WATERTIGHT: the watertight triangle test a Vulkan driver runs, instead of Moeller-Trumbore
-  bool m_anyHitDissolve = false;      // VKRT_OPT_ANYHIT_DISSOLVE: the any-hit stage hello_vulkan.cpp:1185-1191 keeps commented out
-  bool m_skipDeadShadowRays = false;  // VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: same pixels, fewer shadow rays
+  // library options without a counterpart in the reference class (include/vkrt.h vkrt_option); applied by createTopLevelAsGltf.
+  // Tri-state: -1 = not specified, the handle keeps what vkrt_scene_create read from the environment (VKRT_WATERTIGHT, ...);
+  // 0 / 1 = set.  Precedence: this member (config.json) over the environment over the library default.
+  int m_watertight = -1;          // VKRT_OPT_WATERTIGHT: the watertight triangle test a Vulkan driver runs, instead of Moeller-Trumbore
+  int m_anyHitDissolve = -1;      // VKRT_OPT_ANYHIT_DISSOLVE: the any-hit stage hello_vulkan.cpp:1185-1191 keeps commented out
+  int m_skipDeadShadowRays = -1;  // VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: same pixels, fewer shadow rays
   uint32_t m_traceFlags = 0;
   PushConstantPost m_pcPost{1.0f, 0, 0, 0};  // rtMode 0 = hybrid (hello_vulkan.cpp:917), 1 = path tracer
 
@@ -121,7 +128,8 @@ struct AppConfig
   std::string build = "ploc";  // "ploc" (device, default) | "lbvh" (device, fastest build) | "sah" (host)
   std::string mode = "pathtrace";
   bool useShadows = true, useAO = true, useGI = false;  // hello_vulkan.cpp:913-915
-  bool watertight = false, anyHitDissolve = false, skipDeadShadowRays = false;  // library options (include/vkrt.h), all off by default
+  int watertight = -1, anyHitDissolve = -1, skipDeadShadowRays = -1;  // library options (include/vkrt.h): -1 = key absent (environment / library default)
+  int framesPerCall = 1;  // > 1: the frame loop hands that many progressive frames to the library at once (HelloVkrt::pathtraceFrames)
   std::string output;
   std::string scenePath() const { return scenes.at((size_t)scene); }
 };

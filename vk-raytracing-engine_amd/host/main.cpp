@@ -2,6 +2,7 @@
 // (reference main.cpp:117-245 init order, :441-630 frame loop) for the path-tracer mode.
 // No window, no ImGui, no swapchain: reads config.json, renders `frames` progressive frames and
 // writes the rgba32f image (PFM) and a gamma-2.2 preview (PPM, post.frag:39).
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -195,15 +196,21 @@ int main(int argc, char** argv)
     helloVk.m_pcPost.rtMode = hybrid ? 0 : 1;
     helloVk.m_pcRay.useShadows = cfg.useShadows; helloVk.m_pcRay.useAO = cfg.useAO; helloVk.m_pcRay.useGI = cfg.useGI;
     double traceMs = 0;
-    for(int f = 0; f < cfg.frames; f++)                         // main.cpp:441 loop body
+    for(int f = 0; f < cfg.frames;)                             // main.cpp:441 loop body
     {
       helloVk.updateUniformBuffer();                            // main.cpp:503
       helloVk.updateFrame();                                    // main.cpp:504
       helloVk.m_seed = (uint32_t)cfg.seed + (cfg.seedPerFrame ? (uint32_t)f : 0u);
+      int done = 1;
       if(!hybrid)
       {
-        helloVk.pathtrace(cfg.clearColor);                      // main.cpp:507
-        if(gather && f + 1 == cfg.frames)  // every rank keeps accumulating its own strips; the image is needed once, at the end
+        // the camera is at rest for the whole run: "framesPerCall" iterations of the loop go to the library as one call
+        done = std::min(cfg.framesPerCall, cfg.frames - f);
+        if(done > 1)
+          helloVk.pathtraceFrames(cfg.clearColor, done, cfg.seedPerFrame);
+        else
+          helloVk.pathtrace(cfg.clearColor);                    // main.cpp:507
+        if(gather && f + done == cfg.frames)  // every rank keeps accumulating its own strips; the image is needed once, at the end
           gather->gather(helloVk.offscreenDevice(), nullptr);
       }
       else
@@ -214,6 +221,7 @@ int main(int argc, char** argv)
           gather->gather(helloVk.drawPostDevice(), nullptr);
       }
       traceMs += helloVk.lastTraceMs();
+      f += done;
     }
     const vkrt_counters c = helloVk.counters();
     const double rays = (double)(c.rays_closest + c.rays_shadow);

@@ -121,6 +121,22 @@ class Renderer:
                                        C.c_void_p(image.data_ptr()), C.c_void_p(stream.cuda_stream)), "vkrt_pathtrace")
         return image
 
+    def pathtrace_frames(self, pc, cam, width, height, n_frames, seed=0, flags=0, shard=None, image=None, stream=None):
+        """n_frames progressive frames in one call (vkrt_pathtrace_frames): frame i uses pc.frame + i and seed + i."""
+        import torch
+
+        shard = shard or whole_image_shard(width, height)
+        rows = self.shard_rows(shard)
+        if image is None:
+            image = torch.zeros((rows, width, 4), dtype=torch.float32, device=f"cuda:{self.device}")
+        assert image.is_cuda and image.dtype == torch.float32 and image.is_contiguous() and tuple(image.shape) == (rows, width, 4)
+        if stream is None:
+            stream = torch.cuda.current_stream(image.device)
+        opts = abi.TraceOpts(seed & 0xFFFFFFFF, flags)
+        _check(self.lib.vkrt_pathtrace_frames(self._h, C.byref(pc), C.byref(cam), C.byref(opts), C.byref(shard),
+                                              C.c_void_p(image.data_ptr()), int(n_frames), C.c_void_p(stream.cuda_stream)), "vkrt_pathtrace_frames")
+        return image
+
     # ---- hybrid mode (reference rtMode == 0) ---------------------------------------------------------
     def gbuffer_raycast(self, cam, width, height, lights_count=None, clear_color=(1.0, 1.0, 1.0, 1.0), shard=None, stream=None, view_matrix=None):
         """Stand-in for rasterizeGltf: returns dict of torch CUDA planes color/position/normal [rows,W,4], roughMetal [rows,W,2].
