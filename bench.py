@@ -7,11 +7,15 @@ achieved HBM GB/s, Sponza 1080p 8-bounce).
     python bench.py --gpus N ...          (no WORLD_SIZE in the environment: starts the N ranks itself, see self_launch)
     python bench.py --gltf Sponza.gltf --eye X Y Z --center X Y Z [--fov F]   (a supplied scene file instead of the atrium)
 
-A "step" is one vkrt_pathtrace launch = one progressive frame of the workload: the seeded
-procedural Sponza-class atrium (tools/atrium.py; the real Sponza.gltf is not available offline),
-16 spp per frame (PushConstantRay.samples = 16), depth 8, 8 fallback lights, frame index = step
-index (frames > 0 jitter and blend into the resident rgba32f image, raytrace.rgen:44,136-141).
-Scene, BVH, working set and image are resident in HBM before the timed region.
+A "step" is one progressive frame of the workload: the seeded procedural Sponza-class atrium
+(tools/atrium.py; the real Sponza.gltf is not available offline), 16 spp per frame
+(PushConstantRay.samples = 16), depth 8, 8 fallback lights, frame index = step index (frames > 0
+jitter and blend into the resident rgba32f image, raytrace.rgen:44,136-141).  The K timed steps are
+handed to the library --frames-per-call at a time (vkrt_pathtrace_frames: the reference's frame loop
+with the camera at rest, main.cpp:503-508), which keeps consecutive frames in flight; every step is
+still one whole frame with all its rays, and the image after K steps is bit-identical to K
+single-frame calls (tests/test_gpu_frames.py).  Scene, BVH, working set and image are resident in HBM
+before the timed region.
 
   N = 1   BASELINE config 3: 1920x1080.
   N > 1   BASELINE config 4: ONE 3840x2160 frame split into 16-row strips dealt round-robin to the N ranks
@@ -22,9 +26,11 @@ Mrays/s counts the closest-hit + shadow traceRay calls actually issued (device c
 Rank 0 prints ONE JSON line (contract in the task statement) including
   roofline     : dominant kernel k_wf_traverse, priced against the resource that BINDS it: VALU issue.  achieved = VALU
                  wave-instructions per launch (SQ_INSTS_VALU per ray from the committed PMC pass x rays per launch of this
-                 run) / the kernel's mean launch duration (HIP events on the launch stream, this run); peak = the full-rate
-                 issue peak calibrated by tools/issue_microbench.hip (profiles/r02_issue_microbench.json); `frac_nominal`
-                 prices the same rate against the nominal 256 CU x 4 SIMD x 2.4 GHz / 2 cycles = 1228.8 G wave-instr/s.
+                 run) / the kernel's mean launch duration (HIP events on the launch stream, this run); peak = what follows from
+                 the guide: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per full-rate wave64 instruction = 1228.8 G wave-instr/s;
+                 `frac_calibrated` prices the same rate against the full-rate issue rate tools/issue_microbench.hip sustained
+                 (profiles/r02_issue_microbench.json: a pure-VALU load, clock-throttled to 1.5-1.8 GHz; the kernel's own
+                 counter pass runs at ~2.3-2.4 GHz, so that figure flatters and is kept only for continuity with round 3).
                  Sub-blocks, none of them a bound for this kernel: `hbm_own_bytes` (the kernel's own algorithmic bytes --
                  80 B per 8-wide node visited + 48 B per triangle tested + ray / hit records, visit counts from an
                  instrumented launch of this run -- against the 8 TB/s HBM3E peak), `contract` (SURVEY 8d accounting on the
@@ -32,8 +38,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) including
                  L2-resident), `traffic` / `traffic_detail` (fabric-side HBM bytes per launch from separate PMC passes).
                  PMC-derived numbers come from profiles/pmc_*.json; they are tied to the kernel sources by
                  vkrt_amd.source_hash and flagged `pmc_stale` when that file was measured on other sources.
-  cpu_baseline : the CPU oracle (scalar C++ restatement, kind "port") timed on a bounded row sample of the same frame, on all
-                 host threads (`value`) and on one thread (`single_thread`), with the host's CPU model string.
+  cpu_baseline : the CPU oracle (scalar C++ restatement, kind "port") timed on bounded row samples of the same frame: on every
+                 hardware thread this process may use (`value`, `cores`), on 16 threads (`threads_16`: the share of the host a
+                 1-GPU box is sized for) and on one thread (`single_thread`), with the host's CPU model string.
 """
 import argparse
 import json
@@ -157,7 +164,8 @@ def main():
     ap.add_argument("--build", choices=["sah", "lbvh", "ploc"], default="ploc")
     ap.add_argument("--no-textures", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-builder", action="store_true", help="skip the short runs with the builders that were not selected")
+    ap.add_argument("--no-other-builder", action="store_true", help="skip the short runs with the builders that were not selected (and with the Sponza-like tessellation)")
+    ap.add_argument("--frames-per-call", type=int, default=6, help="timed steps handed to the library per vkrt_pathtrace_frames call (1 = one vkrt_pathtrace per step)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--weak", action="store_true", help="N > 1: N x 1080p pixels instead of one fixed 3840x2160 frame")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo for rehearsals")
@@ -210,10 +218,10 @@ def main():
         scaling = "weak"
     elif args.width and args.height:
         W, H = args.width, args.height
-        scaling = "strong" if world > 1 else "weak"
+        scaling = "strong"
     else:
         W, H = (3840, 2160) if world > 1 else (1920, 1080)
-        scaling = "strong" if world > 1 else "weak"  # N = 1: one GPU, nothing to scale; kept "weak" as the contract's default
+        scaling = "strong"  # the frame does not grow with N (N = 1: BASELINE config 3; N > 1: config 4, see config.same_frame_single_gpu_Mrays_s)
     if args.gltf:
         # a supplied scene file (the reference's config.json scenes: Sponza, suntemple, ... -- git-ignored upstream): the product's
         # C++ loader flattens it exactly as for vkrt_render; camera from the command line, defaults = the reference's start-up camera
@@ -251,12 +259,22 @@ def main():
     stream = torch.cuda.current_stream(dev)
     r.reserve(shard, stream)  # no allocation / host synchronisation inside the timed launches
 
-    def step(frame, flags=0):
-        pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
-        r.pathtrace(pc, cam, W, H, seed=frame, flags=flags, shard=shard, image=image, stream=stream)
+    per_call = max(1, args.frames_per_call)
+
+    def render(first_frame, n=1, flags=0, rr=None, sh=None, img=None):
+        """n progressive frames from `first_frame` on: one vkrt_pathtrace (n = 1) or one vkrt_pathtrace_frames call"""
+        rr, sh, img = rr or r, sh or shard, image if img is None else img
+        pc = make_push_constants(samples=args.spp, depth=args.depth, frame=first_frame, lights_count=lights)
+        if n == 1:
+            rr.pathtrace(pc, cam, W, H, seed=first_frame, flags=flags, shard=sh, image=img, stream=stream)
+        else:
+            rr.pathtrace_frames(pc, cam, W, H, n, seed=first_frame, flags=flags, shard=sh, image=img, stream=stream)
+
+    def step(frame, flags=0, n=1):
+        render(frame, n, flags)
         if world > 1:
-            # one gather per frame, overlapped with the next frame's kernels (side stream); the timed region ends with a
-            # device-wide synchronisation, so the last gathered image is complete inside it
+            # one gather per call (the image exists once its last frame is blended), overlapped with the next call's kernels (side
+            # stream); the timed region ends with a device-wide synchronisation, so the last gathered image is complete inside it
             return gather_image(image if args.backend == "nccl" else image.cpu(), H, world, rank, overlap=args.backend == "nccl")
         return image
 
@@ -266,18 +284,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_frames(first_frame, n):
+    def timed_frames(first_frame, n, rr=None):
         sync()
-        r.reset_counters(stream)
+        (rr or r).reset_counters(stream)
         sync()
         t0 = time.perf_counter()
-        for k in range(n):
-            step(first_frame + k)
+        k = 0
+        while k < n:  # exactly n steps (frames), per_call of them per library call
+            m = min(per_call, n - k)
+            if rr is None:
+                step(first_frame + k, n=m)
+            else:
+                render(first_frame + k, m, rr=rr)
+            k += m
         torch.cuda.synchronize(dev)
         t_local = time.perf_counter() - t0  # this rank's own work (before the barrier): load-balance figure
         sync()
         dt = time.perf_counter() - t0
-        c = r.counters()
+        c = (rr or r).counters()
         return dt, t_local, c
 
     for f in range(args.warmup):
@@ -303,6 +327,28 @@ def main():
     torch.cuda.synchronize(dev)
     work = r.counters()
     rays_frame = work["rays_closest"] + work["rays_shadow"]
+
+    # ---- N > 1: the SAME frame on one GPU (rank 0 renders the whole WxH frame, untimed region; the other ranks wait in the
+    #      collectives below): the single-GPU rate the scaling of this frame is to be read against -- the N = 1 line of the
+    #      contract renders BASELINE config 3 (1080p), whose ray rate differs from the 4K frame's by a few per cent -----------
+    same_frame = None
+    if world > 1 and rank == 0:
+        from vkrt_amd.renderer import whole_image_shard
+
+        wsh = whole_image_shard(W, H)
+        whole = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        r.reserve(wsh, stream)
+        render(0, 1, sh=wsh, img=whole)
+        torch.cuda.synchronize(dev)
+        r.reset_counters(stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        render(1, 2, sh=wsh, img=whole)
+        torch.cuda.synchronize(dev)
+        dts = time.perf_counter() - t0
+        cs = r.counters()
+        same_frame = {"Mrays_s": (cs["rays_closest"] + cs["rays_shadow"]) / dts / 1e6, "ms_per_frame": dts / 2 * 1e3, "frames": 2}
+        del whole
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     rr = torch.tensor([float(rays_local)], dtype=torch.float64, device=coll_dev)
@@ -339,13 +385,20 @@ def main():
                             + (f" = BASELINE config 4 frame sharded over {world} GPUs" if world > 1 and (W, H) == (3840, 2160) else ""),
                 "width": W, "height": H, "spp": args.spp, "depth": args.depth, "triangles": info["triangles"],
                 "bvh": args.build, "bvh_nodes": accel["node_count"], "bvh_depth": accel["max_depth"],
-                "parallelism": f"image strips x{world} (16 rows, round-robin) + all_gather per frame (overlapped with the next frame)" if world > 1 else "single GPU",
+                "parallelism": f"image strips x{world} (16 rows, round-robin) + one all_gather per library call (overlapped with the next call)" if world > 1 else "single GPU",
+                "frames_per_call": per_call, "frames_in_flight": r.get_option(abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT),
                 "rays_per_step": rays_total / args.steps,
                 "upload_ms": r.upload_ms, "builds": builds,
                 "per_rank_ms_per_step": rank_ms, "imbalance_max_over_mean": max(rank_ms) / (sum(rank_ms) / len(rank_ms)),
                 "mode": mode, "source_hash": vkrt_amd.source_hash(), "workload_key": key,
             },
         }
+        if same_frame:
+            out["config"]["same_frame_single_gpu_Mrays_s"] = same_frame["Mrays_s"]
+            out["config"]["same_frame_single_gpu_ms_per_frame"] = same_frame["ms_per_frame"]
+            out["config"]["efficiency_vs_same_frame"] = mrays / (world * same_frame["Mrays_s"])
+            out["config"]["same_frame_note"] = ("rank 0 rendered the whole frame alone outside the timed region (2 frames in one call): value / (n_gpus x this) is the "
+                                                "strong-scaling efficiency of THIS frame; the N = 1 line of the contract is BASELINE config 3 (1920x1080), another frame")
         # ---- roofline of the dominant kernel ------------------------------------------------------------------------
         if mode == "wavefront" and trav_launches and trav_launches[-1] > 0:
             n_l = float(np.mean(trav_launches))
@@ -371,8 +424,8 @@ def main():
                 "l2_gather": {"achieved": own_gbs, "peak": L2_GATHER_GBS, "unit": "GB/s", "frac": own_gbs / L2_GATHER_GBS,
                               "note": "NOT a bound: the node array and most of the triangle array are served by the XCDs' L2s: own bytes against the "
                                       "guide's measured L2 gather rate"},
-                "note": "kernel_ms = mean duration of un-overlapped k_wf_traverse launches (timing pass, one sub-frame); value is measured with the "
-                        "default three-sub-frame pipeline.  The kernel is bound by VALU issue (about half of its instructions are half-rate opcodes, so "
+                "note": "kernel_ms = mean duration of un-overlapped k_wf_traverse launches (timing pass, one lane); value is measured with the "
+                        "frames of a call in flight.  The kernel is bound by VALU issue (about half of its instructions are half-rate opcodes, so "
                         "its mix-adjusted ceiling is ~0.65 of the full-rate peak); HBM moves 0.3x the algorithmic bytes (traffic).",
             }
             # the binding resource: VALU issue.  Instructions per ray come from a separate --pmc SQ_INSTS_VALU pass (profiles/pmc_issue.json)
@@ -386,14 +439,18 @@ def main():
                     pi, stale = json.load(open(os.path.join(ROOT, "profiles", "pmc_issue.json"))), True
                 instr = pi["valu_wave_instr_per_ray"] * rays_launch
                 got = instr / (per_launch_ms * 1e-3) / 1e9
-                roof = {"bound": "valu-issue", "achieved": got, "peak": peak, "unit": "G wave-instr/s", "frac": got / peak,
-                        "peak_nominal": ISSUE_NOMINAL_G, "frac_nominal": got / ISSUE_NOMINAL_G, "traffic": None,
+                roof = {"bound": "valu-issue", "achieved": got, "peak": ISSUE_NOMINAL_G, "unit": "G wave-instr/s", "frac": got / ISSUE_NOMINAL_G,
+                        "peak_calibrated": peak, "frac_calibrated": got / peak, "traffic": None,
+                        "calibration_note": "frac_calibrated prices the same rate against the full-rate issue rate a pure-VALU microbenchmark sustained (clock "
+                                            "throttled to 1.5-1.8 GHz under that load); this kernel's own counter pass runs at the clock in "
+                                            "profiles/pmc_issue.json `kernel_clock_ghz` (~2.3-2.4 GHz), so the guide-derived peak is the honest denominator",
+                        "kernel_clock_ghz": pi.get("kernel_clock_ghz"),
                         "valu_wave_instr_per_launch": instr, "valu_wave_instr_per_ray": pi["valu_wave_instr_per_ray"], "pmc_stale": stale,
                         "source": "profiles/pmc_issue.json (SQ_INSTS_VALU per ray" + (", measured on OTHER sources / workload: " + str(pi.get("workload"))
                                   if stale else ", same sources and workload") + ") x rays per launch of this run",
-                        "peak_source": "profiles/r02_issue_microbench.json: best full-rate opcode class at 8 waves/SIMD (v_fma/v_mul/v_add, 2 cycles per wave64 "
-                                       f"instruction per SIMD, clock-throttled); v_cvt_f32_ubyte*, v_min/max(3)_f32, v_cmp, VOP3 integer ops issue at half that rate "
-                                       f"({half:.0f} G/s); peak_nominal = 256 CU x 4 SIMD x 2.4 GHz / 2 cycles"}
+                        "peak_source": "MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per full-rate wave64 VALU instruction (= 157.3 TFLOP/s / 128 flop); "
+                                       "peak_calibrated: profiles/r02_issue_microbench.json, best full-rate opcode class at 8 waves/SIMD; v_cvt_f32_ubyte*, "
+                                       f"v_min/max(3)_f32, v_cmp, VOP3 integer ops issue at half the full rate ({half:.0f} G/s measured)"}
             except Exception:
                 roof = None
             if roof is None:  # no issue profile at all: fall back to the byte view, labelled as what it is
@@ -430,6 +487,27 @@ def main():
                 builds[other]["Mrays_s"] = (c2["rays_closest"] + c2["rays_shadow"]) / dt / 1e6
             builds[args.build]["Mrays_s"] = mrays
             r.build(args.build)
+            # the same building with artist-like tessellation (room-sized wall triangles, 15-m needles, drapery strips; tools/atrium.py
+            # variant "nonuniform"): BASELINE config 3 is Sponza, whose geometry looks like this, not like uniform grids
+            if not args.gltf and args.variant == "default":
+                flat2, info2 = atrium.build_atrium(args.triangles, seed=args.scene_seed, with_textures=not args.no_textures, variant="nonuniform")
+                r2 = Renderer(flat2, device=local_rank, build=args.build)
+                r2.reserve(shard, stream)
+                img2 = torch.zeros_like(image)
+                render(0, 1, rr=r2, img=img2)
+                sync()
+                r2.reset_counters(stream)
+                sync()
+                t0 = time.perf_counter()
+                render(1, 4, rr=r2, img=img2)
+                torch.cuda.synchronize(dev)
+                dt2 = time.perf_counter() - t0
+                c2 = r2.counters()
+                nu = (c2["rays_closest"] + c2["rays_shadow"]) / dt2 / 1e6
+                out["config"]["nonuniform_variant"] = {"Mrays_s": nu, "ratio_to_headline": nu / mrays, "triangles": info2["triangles"], "ms_per_step": dt2 / 4 * 1e3,
+                                                       "note": "same frame, same builder, 4 steps in one call: tools/atrium.py variant nonuniform (Sponza-like tessellation)"}
+                r2.close()
+                del img2
 
         # ---- CPU oracle on a bounded sample: reported CPU baseline + the SURVEY 8d contract accounting ------------------
         if not args.no_cpu_baseline and world == 1:
@@ -440,7 +518,7 @@ def main():
             frame = args.warmup  # the first timed frame
             pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            threads = min(16, avail)  # the 1-GPU box grants 16 CPUs of its host
+            threads = avail  # every hardware thread this process may use (SURVEY 8d "all hardware threads")
 
             def sample(nthreads, seconds):
                 """rows of the frame rendered by the oracle for about `seconds` of wall time on `nthreads` threads"""
@@ -461,10 +539,15 @@ def main():
                     nrows = int(min(H, len(rows) * seconds / max(cpu_s, 1e-6)))
                 return rows, c, cpu_s
 
-            rows, c, cpu_s = sample(threads, args.cpu_seconds)
-            rows1, c1, cpu_s1 = sample(1, 0.6 * args.cpu_seconds)
+            rows, c, cpu_s = sample(threads, 0.8 * args.cpu_seconds)
+            rows1, c1, cpu_s1 = sample(1, 0.5 * args.cpu_seconds)
             cpu_rays = c["rays_closest"] + c["rays_shadow"]
             cpu_rays1 = c1["rays_closest"] + c1["rays_shadow"]
+            t16 = None
+            if threads > 16:  # the share of the host a 1-GPU box is sized for (round 1-3 figures were taken on it)
+                rows16, c16, cpu_s16 = sample(16, 0.5 * args.cpu_seconds)
+                t16 = {"value": (c16["rays_closest"] + c16["rays_shadow"]) / cpu_s16 / 1e6, "unit": "Mrays/s", "cores": 16,
+                       "sample": f"{len(rows16)} rows ({c16['rays_closest'] + c16['rays_shadow']} rays, {cpu_s16:.1f} s)"}
             out["cpu_baseline"] = {
                 "value": cpu_rays / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "sample": f"{len(rows)} evenly spaced rows of frame {frame} of the same {W}x{H} workload ({cpu_rays} rays, {cpu_s:.1f} s), "
@@ -473,6 +556,8 @@ def main():
                                   "sample": f"{len(rows1)} rows ({cpu_rays1} rays, {cpu_s1:.1f} s)"},
                 "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "cpus_available_to_this_process": avail,
             }
+            if t16:
+                out["cpu_baseline"]["threads_16"] = t16
             if "roofline" in out and out["roofline"].get("kernel") == "k_wf_traverse":
                 tb = (64 * c["nodes_visited"] + 48 * c["tris_tested"]) / cpu_rays
                 rl = out["roofline"]

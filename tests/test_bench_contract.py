@@ -31,7 +31,9 @@ def test_algorithmic_bytes_fixture_and_formula():
 def test_default_sizes_follow_baseline_configs():
     """N = 1 -> config 3 (1920x1080); N > 1 -> config 4 (one 3840x2160 frame, strong scaling) unless --weak."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "(3840, 2160) if world > 1 else (1920, 1080)" in src and '"strong" if world > 1' in src
+    assert "(3840, 2160) if world > 1 else (1920, 1080)" in src and 'scaling = "strong"' in src
+    # the N > 1 line carries the single-GPU rate of the SAME frame, so that the first hardware curve is not read against the 1080p line
+    assert "same_frame_single_gpu_Mrays_s" in src and "efficiency_vs_same_frame" in src
 
 
 def test_product_path_of_bench_does_not_touch_the_oracle():
@@ -83,6 +85,29 @@ def test_round3_bench_line_prices_the_binding_resource():
     assert r["traffic"] is not None and r["traffic_detail"]["over_algorithmic_bytes"] < 1.0
     cb = d["cpu_baseline"]
     assert cb["cores"] > 1 and cb["single_thread"]["cores"] == 1 and 0 < cb["single_thread"]["value"] < cb["value"] and cb["cpu_model"]
+
+
+def test_round4_bench_line_says_what_follows_from_the_guide():
+    """Top-level roofline.frac = achieved / the guide-derived issue peak (1228.8 G wave-instr/s); the calibrated figure is kept beside
+    it; the CPU baseline ran on every thread the process may use; the Sponza-like tessellation is quoted next to the headline."""
+    import pytest
+
+    path = os.path.join(ROOT, "profiles", "r04_bench.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-4 bench line committed yet")
+    d = json.loads(open(path).read())
+    r = d["roofline"]
+    assert r["bound"] == "valu-issue" and abs(r["peak"] - 1228.8) < 1e-6 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["peak_calibrated"] < r["peak"] and r["frac"] < r["frac_calibrated"] <= 1.0 and r["pmc_stale"] is False
+    assert r["kernel_clock_ghz"] is None or 1.0 < r["kernel_clock_ghz"] < 3.0
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == cb["cpus_available_to_this_process"] and cb["single_thread"]["cores"] == 1
+    assert cb["cores"] <= 16 or cb["threads_16"]["cores"] == 16
+    cfg = d["config"]
+    assert cfg["frames_per_call"] >= 1 and cfg["frames_in_flight"] >= 1
+    nu = cfg["nonuniform_variant"]
+    assert 0.5 < nu["ratio_to_headline"] < 1.2 and abs(nu["ratio_to_headline"] - nu["Mrays_s"] / d["value"]) < 1e-9
 
 
 def test_round2_bench_line_roofline_is_a_fraction():

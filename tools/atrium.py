@@ -330,8 +330,16 @@ def _build_atrium(target_triangles, seed, with_textures, d, variant=None):
     X0, X1, Y1, Z0, Z1 = -15.0, 15.0, 12.0, -9.0, 9.0
     GZ = 4.6       # colonnade line |z|
     H1 = 5.4       # storey height
-    assert variant in (None, "emissive_mixed_lights", "nonuniform"), variant
-    coarse = variant == "nonuniform"
+    # "nonuniform" = all four ingredients of the artist-like tessellation; "nonuniform:walls,trim" etc. = a subset (attribution runs):
+    #   walls = room-sized floor / wall / slab triangles, trim = mouldings + pilasters + ribbons (needles), cloth = drapery as strips,
+    #   layer = the second drapery layer 1 cm in front of the first
+    parts = set()
+    if variant is not None and variant.startswith("nonuniform"):
+        parts = set(variant.split(":", 1)[1].split(",")) if ":" in variant else {"walls", "trim", "cloth", "layer"}
+        assert parts <= {"walls", "trim", "cloth", "layer"}, variant
+    else:
+        assert variant in (None, "emissive_mixed_lights"), variant
+    coarse = "walls" in parts
     def big(x):  # grid resolution of the large flat surfaces: a few room-sized triangles in the non-uniform variant
         return 1 if coarse else n_(x)
     # floor + roof over the galleries + outer walls (large polygons, coarse grids)
@@ -346,7 +354,7 @@ def _build_atrium(target_triangles, seed, with_textures, d, variant=None):
     for xs in (-1, 1):
         wall = _quad((xs * X1, 0, Z0), (0, 0, Z1 - Z0), (0, Y1, 0), big(24), big(16), (6, 4), flip=(xs < 0))
         place(add_mesh(wall, 4), np.eye(4))
-    if coarse:
+    if "trim" in parts:
         # mouldings and cornices: 3-cm profiles running the length of the building in two pieces (needle triangles, 15 m x 3 cm),
         # on the outer walls, under the gallery slabs and along the colonnade lines; pilaster edges up the walls
         trim = add_mesh(_box((0, 0, 0), (X1 - X0, 0.03, 0.03), (2, 1, 1)), 9)
@@ -392,10 +400,10 @@ def _build_atrium(target_triangles, seed, with_textures, d, variant=None):
     ncloth = 8
     for i in range(ncloth):
         # non-uniform variant: the drapery as long thin strips (many columns, few rows) with a second layer 1 cm in front of it
-        cl = add_mesh(_cloth(3.2, 4.2, n_(260, 8), n_(10, 2), rng) if coarse else _cloth(3.2, 4.2, n_(84, 8), n_(72, 8), rng), 10 + i % 4)
+        cl = add_mesh(_cloth(3.2, 4.2, n_(260, 8), n_(10, 2), rng) if "cloth" in parts else _cloth(3.2, 4.2, n_(84, 8), n_(72, 8), rng), 10 + i % 4)
         x = X0 + 4.0 + (X1 - X0 - 8.0) * (i // 2) / max(1, ncloth // 2 - 1)
         place(cl, _trs((x, 9.6, (-1 if i % 2 else 1) * 2.1), ry=0.5 * np.pi + 0.1 * i))
-        if coarse:
+        if "layer" in parts:
             place(cl, _trs((x + 0.01, 9.58, (-1 if i % 2 else 1) * 2.1), ry=0.5 * np.pi + 0.1 * i + 0.004))
 
     # floor clutter: blobs and vases, unique and instanced

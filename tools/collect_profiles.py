@@ -44,7 +44,8 @@ def tie(out, logname, dom_key_per_launch):
             out[k_ray] = out[k_launch] / out["rays_per_launch"]
 
 
-def per_kernel(dirname, counter):
+def per_kernel(dirname, counter, durations=None):
+    """Sum and launch count of `counter` per kernel; durations (dict): summed End - Start of those launches in ns."""
     f = newest(os.path.join(src, dirname, "*", "*counter_collection.csv"))
     tot, n = collections.defaultdict(float), collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
@@ -52,6 +53,8 @@ def per_kernel(dirname, counter):
             k = r["Kernel_Name"].split("(")[0]
             tot[k] += float(r["Counter_Value"])
             n[k] += 1
+            if durations is not None:
+                durations[k] = durations.get(k, 0.0) + float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return tot, n
 
 
@@ -84,7 +87,10 @@ json.dump(out, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
 if glob.glob(os.path.join(src, "pmc_valu", "*", "*counter_collection.csv")):
     valu, nv = per_kernel("pmc_valu", "SQ_INSTS_VALU")
     waves, _ = per_kernel("pmc_valu", "SQ_WAVES")
-    issue = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES (kernel-trace only, VKRT_WF_SUBFRAMES=1) on `python3 bench.py --no-cpu-baseline`",
+    dur = {}
+    gui, ng = per_kernel("pmc_valu", "GRBM_GUI_ACTIVE", dur)  # (absent from passes older than round 4)
+    issue = {"source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE (kernel-trace only, one lane: VKRT_WF_SUBFRAMES=1 VKRT_WF_FRAMES_IN_FLIGHT=1) on "
+                       "`python3 bench.py --no-cpu-baseline`",
              "unit": "VALU wave-instructions", "kernels": {}}
     for k in valu:
         if k.strip().startswith(("void k_wf", "k_wf")):
@@ -92,6 +98,12 @@ if glob.glob(os.path.join(src, "pmc_valu", "*", "*counter_collection.csv")):
                                            "waves_per_launch": waves.get(k, 0.0) / max(nv[k], 1)}
     d = next((k for k in issue["kernels"] if "traverse" in k), None)
     if d:
+        raw = next((k for k in gui if k.strip() == d), None)
+        if raw and dur.get(raw):
+            # GRBM_GUI_ACTIVE counts busy cycles of every XCD (8 on this part): cycles per XCD / the launches' own durations = the shader
+            # clock the kernel ran at under the counter pass (the issue microbenchmark throttles to 1.5-1.8 GHz, this kernel does not)
+            issue["kernel_clock_ghz"] = gui[raw] / 8.0 / dur[raw]
+            issue["kernel_clock_note"] = "GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / summed launch durations of the dominant kernel in the same pass"
         issue["dominant_kernel"] = d
         issue["valu_wave_instr_per_launch"] = issue["kernels"][d]["valu_wave_instr_per_launch"]
         tie(issue, "pmc_valu.log", [("valu_wave_instr_per_launch", "valu_wave_instr_per_ray")])

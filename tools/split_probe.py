@@ -15,7 +15,7 @@ SPP = int(os.environ.get("PROBE_SPP", 16))
 FRAMES = int(os.environ.get("PROBE_FRAMES", 3))
 kind = os.environ.get("BUILD", "ploc")
 extra = {int(k): int(v) for k, v in (kv.split("=") for kv in os.environ.get("PROBE_OPTS", "").split(",") if kv)}
-for variant in os.environ.get("PROBE_VARIANTS", "default,nonuniform").split(","):
+for variant in os.environ.get("PROBE_VARIANTS", "default;nonuniform").split(";"):
     flat, info = atrium.build_atrium(262144, seed=1, **({} if variant == "default" else {"variant": variant}))
     cam = host_py.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA)
     r = Renderer(flat, device=0, build=None)
@@ -45,6 +45,9 @@ for variant in os.environ.get("PROBE_VARIANTS", "default,nonuniform").split(",")
         wr = w["rays_closest"] + w["rays_shadow"]
         print(json.dumps({"variant": variant, "build": kind, "budget": budget, "opts": extra, "ms_per_frame": round(best, 3), "Mrays_s": round(rays / best / 1e3, 1),
                           "nodes_per_ray": round(w["nodes_visited"] / wr, 2), "tris_per_ray": round(w["tris_tested"] / wr, 2),
+                          "node_lane_eff": round(w["nodes_visited"] / max(64 * w["wave_node_steps"], 1), 3), "tri_lane_eff": round(w["tris_tested"] / max(64 * w["wave_tri_steps"], 1), 3),
+                          "wave_node_steps_per_kray": round(1e3 * w["wave_node_steps"] / wr, 2), "wave_tri_steps_per_kray": round(1e3 * w["wave_tri_steps"] / wr, 2),
+                          "shadow_frac": round(w["rays_shadow"] / wr, 3), "hits_per_closest": round(w["hits"] / max(w["rays_closest"], 1), 3), "rays_M": round(rays / 1e6, 1),
                           "triangles": a["triangle_count"], "references": a["reference_count"], "nodes": a["node_count"], "depth": a["max_depth"],
                           "sah": round(a["sah_cost"], 2), "build_ms": round(build_ms, 1), "anyhit_order": r.get_option(abi.VKRT_INFO_ANYHIT_ORDER),
                           "faults": c["traversal_faults"]}), flush=True)
