@@ -1070,3 +1070,62 @@ def test_config3_full_size_rows_sample_with_the_watertight_test():
             a = ref[np.isin(rows, common)]
             b = _C3_MEMO["ref"][np.isin(np.linspace(0, H - 1, 24).astype(np.uint32), common)]
             assert abs(float(a[..., :3].mean()) - float(b[..., :3].mean())) < 0.02 * float(b[..., :3].mean())
+
+
+def test_gbuffer_on_a_dissolve_scene_keeps_the_smallest_id_rule(cornell_flat):
+    """Coincident triangles, the later one translucent, under VKRT_OPT_ANYHIT_DISSOLVE: the records of the translucent copy carry the
+    stage's flag in bit 31 of their id word.  The ray-cast G-buffer treats every triangle as opaque (a raster pass has no any-hit
+    stage) and must still break the tie towards the SMALLEST triangle id -- the opaque original -- not towards the flagged record
+    (whose unmasked id word is negative), and tmax stays exclusive.  Both node layouts, all builders; the traced passes see the stage."""
+    import copy
+
+    import oracle_py
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import MAT_DTYPE, NODE_DTYPE, PRIM_DTYPE, make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    flat = copy.deepcopy(cornell_flat)
+    mats = np.zeros(len(flat.materials) + 1, MAT_DTYPE)
+    mats[:-1] = flat.materials
+    mats[-1] = flat.materials[0]
+    mats[-1]["pbrBaseColorFactor"] = (0.1, 0.9, 0.2, 0.5)  # translucent green: dissolve 0.5
+    new_m = len(mats) - 1
+    prims, nodes = list(flat.prim_meshes), list(flat.nodes)
+    n_dup = 0
+    for k in range(len(flat.nodes)):  # a translucent copy of every second instance, appended behind the originals (larger ids)
+        if k % 2:
+            continue
+        p = np.array(flat.prim_meshes[int(flat.nodes[k]["primMesh"])], PRIM_DTYPE)
+        p["materialIndex"] = new_m
+        prims.append(p)
+        nd = np.array(flat.nodes[k], NODE_DTYPE)
+        nd["primMesh"] = len(prims) - 1
+        nodes.append(nd)
+        n_dup += 1
+    assert n_dup > 0
+    flat.materials = mats
+    flat.prim_meshes = np.array(prims, PRIM_DTYPE)
+    flat.nodes = np.array(nodes, NODE_DTYPE)
+    W, H = 160, 120
+    cam = default_camera(W, H)
+    orc = oracle_py.OracleScene(flat)
+    orc.set_dissolve(True)
+    go = orc.gbuffer(cam, W, H, lights_count=1)
+    orc_opaque = oracle_py.OracleScene(flat)
+    g_plain = orc_opaque.gbuffer(cam, W, H, lights_count=1)
+    for k in go:  # (the oracle's G-buffer does not see the stage either)
+        assert np.array_equal(go[k].view(np.uint32), g_plain[k].view(np.uint32)), k
+    for kind, opts in (("ploc", {}), ("lbvh", {abi.VKRT_OPT_BVH_LAYOUT: 0}), ("sah", {}), ("ploc", {abi.VKRT_OPT_WATERTIGHT: 1})):
+        if opts.get(abi.VKRT_OPT_WATERTIGHT):
+            orc.set_watertight(True)
+            go = orc.gbuffer(cam, W, H, lights_count=1)
+        r = Renderer(flat, device=0, build=kind, options={**opts, abi.VKRT_OPT_ANYHIT_DISSOLVE: 1})
+        g = r.gbuffer_raycast(cam, W, H, lights_count=1)
+        for k in go:
+            assert mismatch_fraction(g[k].cpu().numpy(), go[k]) < 1e-3, (kind, opts, k)  # (with the flag unmasked: every pixel of a doubled surface)
+        # the traced part does run the stage: translucent copies let about half of the rays through, the image differs from the opaque one
+        pc = make_push_constants(samples=2, depth=3, frame=0, lights_count=1)
+        img = r.pathtrace(pc, cam, W, H, seed=5).cpu().numpy()
+        ref, _ = orc.render(pc, cam, W, H, seed=5)
+        assert mismatch_fraction(img, ref) < 1e-4
+        r.close()

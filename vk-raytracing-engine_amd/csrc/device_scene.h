@@ -23,16 +23,19 @@ static_assert(sizeof(DevInstance) == 96, "DevInstance");
 // Shading-side repack (done once at upload; the API still takes the reference's SoA arrays):
 // the per-CU L1/TA processes one 16-byte lane-load per tag lookup, so records are laid out for few,
 // wide, aligned loads instead of the ~70 dword loads per hit that the raw SoA layout needs.
-//   vertex  : 2 x float4 = (pos.xyz, nrm.x) (nrm.y, nrm.z, uv.x, uv.y); tangents stay float4
+//   vertex  : 3 x float4 = (pos.xyz, nrm.x) (nrm.y, nrm.z, uv.x, uv.y) (tangent.xyzw): 48 bytes, one or two cache lines per vertex
+//             (round 4: the tangent used to live in an array of its own, a third line per vertex)
 //   material: 128 bytes = GltfPBRMaterial (52 B) padded to four aligned float4 + the descriptors of its four
 //             textures (base colour, metallic-roughness, normal, emissive), so a hit reaches its texels in
 //             one hop from the material record instead of two (no separate descriptor-table lookup)
+#define VKRT_VERTEX_QUADS 3
+#define VKRT_VERTEX_BYTES 48u
 struct DevTexRef
 {
   uint32_t offset;  // first texel in the RGBA8 pool (0 when invalid)
   uint32_t wh;      // width | height << 16 (1 | 1 << 16 when invalid)
   uint32_t flags;   // bit 0: index refers to an uploaded texture; bit 1: sRGB
-  uint32_t pad;
+  uint32_t quads;   // first record of the texture's level 0 in the footprint pool (DevScene::texQuads; 0 when invalid or no such pool)
 };
 #define VKRT_TEXREF_BASE 0
 #define VKRT_TEXREF_MR 1
@@ -69,15 +72,17 @@ struct DevTexture
 struct DevScene
 {
   const float* positions;     // vec3[]
-  const float* tangents;      // vec4[]
   const uint32_t* indices;
-  const float4* vertexPN;     // 2 float4 per vertex (see above)
+  const float4* vertexPN;     // VKRT_VERTEX_QUADS float4 per vertex (see above)
   const DevMaterial* materials;
   const GltfLight* lights;
   const DevInstance* instances;
   const DevTexture* textures;
   const uint32_t* texMips;    // [textureCount][VKRT_MAX_MIPS]: first texel of every mip level (hello_vulkan.cpp:496 cmdGenerateMipmaps)
   const uint32_t* texels;     // RGBA8 pool (all levels)
+  const uint4* texQuads;      // footprint pool of every texture's level 0, or NULL: record (x, y) = the texels (x, y) (x+1, y) (x, y+1) (x+1, y+1) with REPEAT
+                              // wrap -- the 2x2 footprint of a bilinear tap as ONE 16-byte lane-load instead of four 4-byte ones (the hit shader is
+                              // bound by the L1's lane-load rate, not by bytes: profiles/r04_experiments.md #115)
   const float* srgbLut;       // 512 floats: [0,256) sRGB decode of i/255, [256,512) i/255 (UNORM decode)
   const float4* nodes;
   const float4* tris;

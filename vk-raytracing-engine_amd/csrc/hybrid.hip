@@ -147,8 +147,7 @@ __global__ __launch_bounds__(HY_BLOCK) void k_gbuffer(const HybridParams H)
 #pragma unroll
       for(int k = 0; k < 3; k++)  // vert_shader.vert:60-74 per vertex, then the rasteriser's barycentric interpolation
       {
-        const float4 a = sc.vertexPN[2 * vi[k]], b = sc.vertexPN[2 * vi[k] + 1];
-        const float4 tq = ((const float4*)sc.tangents)[vi[k]];
+        const float4 a = sc.vertexPN[VKRT_VERTEX_QUADS * vi[k]], b = sc.vertexPN[VKRT_VERTEX_QUADS * vi[k] + 1], tq = sc.vertexPN[VKRT_VERTEX_QUADS * vi[k] + 2];
         const f3 pw = xformPoint(in, mk3(a.x, a.y, a.z));
         const f3 n = normalize3(xformNormal(in, mk3(a.w, b.x, b.y)));
         f3 t = normalize3(xformNormal(in, mk3(tq.x, tq.y, tq.z)));

@@ -38,6 +38,28 @@ VKRT_DEV const float* ldsTexelLut(const DevScene& sc, float* lds512)
 
 struct f4 { float x, y, z, w; };
 
+// Gathers of the hit shader go through buffer descriptors (four SGPRs built from a kernel-argument pointer) with a 32-bit byte
+// offset per lane instead of a 64-bit flat address per lane: one VGPR per address instead of two.  The shader holds 16 texel
+// addresses + 8 record addresses at its register peak, so this is what takes it from 140 to under 128 VGPRs, i.e. from three to four
+// waves per SIMD without a spill (profiles/r04_experiments.md #114).  Every table is < 4 GiB (vkrt_scene_create refuses larger ones);
+// the range check of the descriptor is left open (all ones): indices are validated at upload, as before.
+#if defined(VKRT_SHADE_FLAT_LOADS)
+struct BufView { const char* p; };
+VKRT_DEV BufView bufView(const void* p) { return BufView{(const char*)p}; }
+VKRT_DEV float4 bufLoad4(BufView b, uint32_t byteOffset) { return *(const float4*)(b.p + byteOffset); }
+VKRT_DEV uint32_t bufLoad1(BufView b, uint32_t byteOffset) { return *(const uint32_t*)(b.p + byteOffset); }
+#else
+typedef unsigned vkrt_v4u __attribute__((ext_vector_type(4)));
+struct BufView { __amdgpu_buffer_rsrc_t r; };
+VKRT_DEV BufView bufView(const void* p) { return BufView{__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)0xffffffffu, 0x00020000)}; }
+VKRT_DEV float4 bufLoad4(BufView b, uint32_t byteOffset)
+{
+  const vkrt_v4u v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)byteOffset, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+VKRT_DEV uint32_t bufLoad1(BufView b, uint32_t byteOffset) { return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)byteOffset, 0, 0); }
+#endif
+
 // i mod n in [0, n) for n > 0 (REPEAT addressing); power-of-two sizes take the mask path
 VKRT_DEV int wrapi(int i, int n)
 {
@@ -348,17 +370,26 @@ VKRT_DEV void closestHitFront(const DevScene& sc, const RayHit& hit, const uint3
   const uint32_t i0 = ts.x, i1 = ts.y, i2 = ts.z, matIndex = ts.w;
   const f3 b = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);  // rchit:68
 
-  const float4 a0 = sc.vertexPN[2 * i0], b0 = sc.vertexPN[2 * i0 + 1];
-  const float4 a1 = sc.vertexPN[2 * i1], b1 = sc.vertexPN[2 * i1 + 1];
-  const float4 a2 = sc.vertexPN[2 * i2], b2 = sc.vertexPN[2 * i2 + 1];
-  const float4 tq0 = ((const float4*)sc.tangents)[i0];
-  const float4 tq1 = ((const float4*)sc.tangents)[i1];
-  const float4 tq2 = ((const float4*)sc.tangents)[i2];
-  // material: eight aligned 16-byte loads of the 128-byte record (factors + the four texture descriptors)
-  const float4* mq = (const float4*)&sc.materials[matIndex];
-  const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3];
-  const float4 d0 = mq[4], d1 = mq[5], d2 = mq[6], d3 = mq[7];
-  const DevInstance in = sc.instances[instId];
+  const BufView vPN = bufView(sc.vertexPN), vMat = bufView(sc.materials), vInst = bufView(sc.instances);
+  const float4 a0 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i0), b0 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i0 + 16u), tq0 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i0 + 32u);
+  const float4 a1 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i1), b1 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i1 + 16u), tq1 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i1 + 32u);
+  const float4 a2 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i2), b2 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i2 + 16u), tq2 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i2 + 32u);
+  // material: eight aligned 16-byte loads of the 128-byte record (factors + the four texture descriptors).  (Staging the material
+  // and instance tables in LDS per workgroup -- 14 ds_read_b128 instead of 14 lane-loads that nearly always hit L1 -- made the stage
+  // 9 % SLOWER: the copy costs more than those hot loads did; profiles/r04_experiments.md #115)
+  const uint32_t mo = 128u * matIndex;
+  const float4 m0 = bufLoad4(vMat, mo), m1 = bufLoad4(vMat, mo + 16u), m2 = bufLoad4(vMat, mo + 32u), m3 = bufLoad4(vMat, mo + 48u);
+  const float4 d0 = bufLoad4(vMat, mo + 64u), d1 = bufLoad4(vMat, mo + 80u), d2 = bufLoad4(vMat, mo + 96u), d3 = bufLoad4(vMat, mo + 112u);
+  DevInstance in;
+  {
+    const uint32_t io = 96u * instId;  // 96-byte record: six aligned 16-byte loads
+    const float4 q0 = bufLoad4(vInst, io), q1 = bufLoad4(vInst, io + 16u), q2 = bufLoad4(vInst, io + 32u), q3 = bufLoad4(vInst, io + 48u), q4 = bufLoad4(vInst, io + 64u),
+                 q5 = bufLoad4(vInst, io + 80u);
+    in.o2w[0] = q0.x; in.o2w[1] = q0.y; in.o2w[2] = q0.z; in.o2w[3] = q0.w; in.o2w[4] = q1.x; in.o2w[5] = q1.y; in.o2w[6] = q1.z; in.o2w[7] = q1.w;
+    in.o2w[8] = q2.x; in.o2w[9] = q2.y; in.o2w[10] = q2.z; in.o2w[11] = q2.w;
+    in.w2o[0] = q3.x; in.w2o[1] = q3.y; in.w2o[2] = q3.z; in.w2o[3] = q3.w; in.w2o[4] = q4.x; in.w2o[5] = q4.y; in.w2o[6] = q4.z; in.w2o[7] = q4.w;
+    in.w2o[8] = q5.x; in.primMesh = __float_as_int(q5.y); in.pad[0] = 0; in.pad[1] = 0;
+  }
   GltfPBRMaterial mat;
   mat.pbrBaseColorFactor[0] = m0.x; mat.pbrBaseColorFactor[1] = m0.y; mat.pbrBaseColorFactor[2] = m0.z; mat.pbrBaseColorFactor[3] = m0.w;
   mat.pbrBaseColorTexture = __float_as_int(m1.x); mat.metallicFactor = m1.y; mat.roughnessFactor = m1.z;
@@ -384,11 +415,34 @@ VKRT_DEV void closestHitFront(const DevScene& sc, const RayHit& hit, const uint3
   VKRT_FOOTPRINT(d0, wantB, tB);
   VKRT_FOOTPRINT(d1, wantM, tM);
 #undef VKRT_FOOTPRINT
-  const uint32_t* __restrict__ tex = sc.texels;
-  const uint32_t e00 = tex[tE.i00], e10 = tex[tE.i10], e01 = tex[tE.i01], e11 = tex[tE.i11];
-  const uint32_t n00 = tex[tN.i00], n10 = tex[tN.i10], n01 = tex[tN.i01], n11 = tex[tN.i11];
-  const uint32_t c00 = tex[tB.i00], c10 = tex[tB.i10], c01 = tex[tB.i01], c11 = tex[tB.i11];
-  const uint32_t r00 = tex[tM.i00], r10 = tex[tM.i10], r01 = tex[tM.i01], r11 = tex[tM.i11];
+  uint32_t e00, e10, e01, e11, n00, n10, n01, n11, c00, c10, c01, c11, r00, r10, r01, r11;
+  if(sc.texQuads)
+  {
+    // one 16-byte record per tap: the 2x2 footprint at (x0, y0) with the wrap already applied (DevScene::texQuads); the record
+    // number is the level-0 texel number of i00 moved from the texel pool's numbering to the footprint pool's
+    const BufView quads = bufView(sc.texQuads);
+#define VKRT_QUAD(q, tap, want, a, b, c, d)                                                                                            \
+  {                                                                                                                                    \
+    const uint32_t rec_ = ((want) && (__float_as_uint(q.z) & 1u) != 0u) ? (tap.i00 - __float_as_uint(q.x)) + __float_as_uint(q.w) : 0u; \
+    const float4 v_ = bufLoad4(quads, 16u * rec_);                                                                                     \
+    a = __float_as_uint(v_.x); b = __float_as_uint(v_.y); c = __float_as_uint(v_.z); d = __float_as_uint(v_.w);                        \
+  }
+    VKRT_QUAD(d3, tE, wantE, e00, e10, e01, e11)
+    VKRT_QUAD(d2, tN, wantN, n00, n10, n01, n11)
+    VKRT_QUAD(d0, tB, wantB, c00, c10, c01, c11)
+    VKRT_QUAD(d1, tM, wantM, r00, r10, r01, r11)
+#undef VKRT_QUAD
+  }
+  else
+  {
+    const BufView tex = bufView(sc.texels);
+#define VKRT_TEXEL(i) bufLoad1(tex, 4u * (i))
+    e00 = VKRT_TEXEL(tE.i00); e10 = VKRT_TEXEL(tE.i10); e01 = VKRT_TEXEL(tE.i01); e11 = VKRT_TEXEL(tE.i11);
+    n00 = VKRT_TEXEL(tN.i00); n10 = VKRT_TEXEL(tN.i10); n01 = VKRT_TEXEL(tN.i01); n11 = VKRT_TEXEL(tN.i11);
+    c00 = VKRT_TEXEL(tB.i00); c10 = VKRT_TEXEL(tB.i10); c01 = VKRT_TEXEL(tB.i01); c11 = VKRT_TEXEL(tB.i11);
+    r00 = VKRT_TEXEL(tM.i00); r10 = VKRT_TEXEL(tM.i10); r01 = VKRT_TEXEL(tM.i01); r11 = VKRT_TEXEL(tM.i11);
+#undef VKRT_TEXEL
+  }
 
   const f3 pos = mk3(a0.x, a0.y, a0.z) * b.x + mk3(a1.x, a1.y, a1.z) * b.y + mk3(a2.x, a2.y, a2.z) * b.z;
   const f3 worldPos = xformPoint(in, pos);

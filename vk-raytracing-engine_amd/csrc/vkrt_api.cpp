@@ -346,19 +346,19 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
 
   DevScene& D = s->dev;
   if((rc = upload(s, d->positions, 3 * (size_t)d->vertex_count, &D.positions)) != VKRT_OK) return bail(rc);
-  if((rc = upload(s, d->tangents, 4 * (size_t)d->vertex_count, &D.tangents)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, d->indices, (size_t)d->index_count, &D.indices)) != VKRT_OK) return bail(rc);
   // (normals / uv travel inside vertexPN; the ePrimLookup indirection of hello_vulkan.cpp:363-368 is resolved per triangle
   // at build time into triShade, so neither is uploaded in its raw form)
-  // interleaved (position, normal, uv) records for the closest-hit attribute fetch (rchit:41-66)
+  // interleaved (position, normal, uv, tangent) records for the closest-hit attribute fetch (rchit:41-66)
   {
-    std::vector<float> pn((size_t)d->vertex_count * 8);
+    std::vector<float> pn((size_t)d->vertex_count * 4 * VKRT_VERTEX_QUADS);
     for(uint32_t v = 0; v < d->vertex_count; v++)
     {
-      float* o = &pn[(size_t)v * 8];
+      float* o = &pn[(size_t)v * 4 * VKRT_VERTEX_QUADS];
       o[0] = d->positions[3 * (size_t)v]; o[1] = d->positions[3 * (size_t)v + 1]; o[2] = d->positions[3 * (size_t)v + 2];
       o[3] = d->normals[3 * (size_t)v]; o[4] = d->normals[3 * (size_t)v + 1]; o[5] = d->normals[3 * (size_t)v + 2];
       o[6] = d->texcoords0[2 * (size_t)v]; o[7] = d->texcoords0[2 * (size_t)v + 1];
+      for(int k = 0; k < 4; k++) o[8 + k] = d->tangents[4 * (size_t)v + k];
     }
     const float* pnDev = nullptr;
     if((rc = upload(s, pn.data(), pn.size(), &pnDev)) != VKRT_OK) return bail(rc);
@@ -389,6 +389,39 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   std::vector<DevTexture> table(d->texture_count);
   std::vector<uint32_t> mipTable((size_t)d->texture_count * VKRT_MAX_MIPS, 0u);
   std::vector<uint32_t> pool;
+  // footprint pool (DevScene::texQuads): 16 bytes per level-0 texel; built when it stays below 2 GiB and VKRT_TEX_QUADS=0 is not set
+  // (test hook: the path tracer then gathers the four texels of a tap one by one, as it did up to round 3; same values either way)
+  std::vector<uint32_t> quadFirst(d->texture_count, 0u);
+  uint64_t quadTotal = 1;  // record 0 = white dummy (hits without a texture read it and discard it)
+  for(uint32_t t = 0; t < d->texture_count; t++)
+  {
+    quadFirst[t] = (uint32_t)std::min<uint64_t>(quadTotal, 0xffffffffull);
+    quadTotal += (uint64_t)d->textures[t].width * d->textures[t].height;
+  }
+  const char* quadEnv = getenv("VKRT_TEX_QUADS");
+  const bool wantQuads = quadTotal * 16ull < (2ull << 30) && !(quadEnv && atoi(quadEnv) == 0);
+  std::vector<uint32_t> quads;
+  if(wantQuads)
+  {
+    quads.assign((size_t)quadTotal * 4, 0xffffffffu);
+    for(uint32_t t = 0; t < d->texture_count; t++)
+    {
+      const vkrt_texture& tx = d->textures[t];
+      const uint32_t* src = (const uint32_t*)tx.rgba8;
+      uint32_t* dst = &quads[(size_t)quadFirst[t] * 4];
+      for(uint32_t y = 0; y < tx.height; y++)
+      {
+        const uint32_t y1 = y + 1 == tx.height ? 0 : y + 1;
+        for(uint32_t x = 0; x < tx.width; x++)
+        {
+          const uint32_t x1 = x + 1 == tx.width ? 0 : x + 1;
+          uint32_t* q = dst + ((size_t)y * tx.width + x) * 4;
+          memcpy(&q[0], &src[(size_t)y * tx.width + x], 4); memcpy(&q[1], &src[(size_t)y * tx.width + x1], 4);
+          memcpy(&q[2], &src[(size_t)y1 * tx.width + x], 4); memcpy(&q[3], &src[(size_t)y1 * tx.width + x1], 4);
+        }
+      }
+    }
+  }
   for(uint32_t t = 0; t < d->texture_count; t++)
   {
     const vkrt_texture& tx = d->textures[t];
@@ -430,7 +463,7 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
         const DevTexture& t = table[(size_t)idx[k]];
         if(t.width == 0u || t.height == 0u || t.width > 65535u || t.height > 65535u)
           return bail(fail(VKRT_ERR_UNSUPPORTED, "texture %d is %ux%u (supported: 1..65535 per side)", idx[k], t.width, t.height));
-        r = DevTexRef{t.offset, t.width | (t.height << 16), 1u | ((t.srgb & 1u) ? 2u : 0u), 0u};
+        r = DevTexRef{t.offset, t.width | (t.height << 16), 1u | ((t.srgb & 1u) ? 2u : 0u), wantQuads ? quadFirst[(size_t)idx[k]] : 0u};
       }
     }
   }
@@ -438,6 +471,17 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
   if((rc = upload(s, table.data(), table.size(), &D.textures)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, mipTable.data(), mipTable.size(), &D.texMips)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, pool.data(), pool.size(), &D.texels)) != VKRT_OK) return bail(rc);
+  D.texQuads = nullptr;
+  if(wantQuads)
+  {
+    const uint32_t* qd = nullptr;
+    if((rc = upload(s, quads.data(), quads.size(), &qd)) != VKRT_OK) return bail(rc);
+    D.texQuads = (const uint4*)qd;
+  }
+  // the hit shader addresses its tables with 32-bit byte offsets (shade.h BufView): refuse what does not fit
+  if((uint64_t)pool.size() * 4 >= (4ull << 30) || (uint64_t)d->vertex_count * VKRT_VERTEX_BYTES >= (4ull << 30) || (uint64_t)d->material_count * 128 >= (4ull << 30) ||
+     (uint64_t)d->node_count * 96 >= (4ull << 30))
+    return bail(fail(VKRT_ERR_UNSUPPORTED, "scene tables of 4 GiB and more are not supported (texel pool %zu texels, %u vertices)", pool.size(), d->vertex_count));
   const float* lutDev = nullptr;
   if((rc = upload(s, lut, 512, &lutDev)) != VKRT_OK) return bail(rc);
   D.srgbLut = lutDev;

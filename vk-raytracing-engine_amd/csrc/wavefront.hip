@@ -72,6 +72,13 @@ VKRT_DEV float4* plane(const WfBuffers& B, int parity, int type, int k)
   return B.planes + ((size_t)((parity * WF_TYPES + type) * WF_PLANES + k)) * B.capacity;
 }
 VKRT_DEV unsigned* countOf(const WfBuffers& B, int parity, int type) { return &B.ctrl[parity * 4 + type]; }
+// record i of a plane: the plane's base is uniform (kernel arguments, round parity, the workgroup's stream type) and the record's byte
+// offset fits 32 bits (capacity < 2^28 paths, checked at launch), so the access is "scalar base + 32-bit lane offset": one address
+// VGPR per access instead of two (the shade kernel holds a dozen of them at once)
+VKRT_DEV float4* rec(const WfBuffers& B, int parity, int type, int k, unsigned i)
+{
+  return (float4*)((char*)plane(B, parity, type, k) + (size_t)(i * 16u));
+}
 
 // Stream records are written by one kernel and consumed by the next one or two (the traversal kernel reads the ray planes, the shade
 // kernel the rest; the direction and seed planes are read by both): no later round reads them again, so they are fetched with non-temporal
@@ -93,7 +100,7 @@ VKRT_DEV unsigned packFlags(const LaneState& L)
 // state common to all streams (S0..S2) -> lane
 VKRT_DEV void loadCommon(const TraceParams& P, const WfBuffers& B, int parity, int type, unsigned i, LaneState& L)
 {
-  const float4 s0 = wfLoad(&plane(B, parity, type, WF_S0)[i]), s1 = wfLoad(&plane(B, parity, type, WF_S1)[i]), s2 = wfLoad(&plane(B, parity, type, WF_S2)[i]);
+  const float4 s0 = wfLoad(rec(B, parity, type, WF_S0, i)), s1 = wfLoad(rec(B, parity, type, WF_S1, i)), s2 = wfLoad(rec(B, parity, type, WF_S2, i));
   const unsigned flags = __float_as_uint(s1.w), pix = __float_as_uint(s2.w);
   L.curWeight = mk3(s0.x, s0.y, s0.z); L.prd.seed = __float_as_uint(s0.w);
   L.hitValue = mk3(s1.x, s1.y, s1.z);
@@ -113,16 +120,16 @@ VKRT_DEV void loadCommon(const TraceParams& P, const WfBuffers& B, int parity, i
 
 VKRT_DEV void storeState(const WfBuffers& B, int parity, int type, unsigned i, const LaneState& L, f3 weight)
 {
-  wfStore(&plane(B, parity, type, WF_S0)[i], make_float4(weight.x, weight.y, weight.z, __uint_as_float(L.prd.seed)));
-  wfStore(&plane(B, parity, type, WF_S1)[i], make_float4(L.hitValue.x, L.hitValue.y, L.hitValue.z, __uint_as_float(packFlags(L))));
-  wfStore(&plane(B, parity, type, WF_S2)[i], make_float4(L.hitValues.x, L.hitValues.y, L.hitValues.z, __uint_as_float(L.px | (L.lrow << 16))));
+  wfStore(rec(B, parity, type, WF_S0, i), make_float4(weight.x, weight.y, weight.z, __uint_as_float(L.prd.seed)));
+  wfStore(rec(B, parity, type, WF_S1, i), make_float4(L.hitValue.x, L.hitValue.y, L.hitValue.z, __uint_as_float(packFlags(L))));
+  wfStore(rec(B, parity, type, WF_S2, i), make_float4(L.hitValues.x, L.hitValues.y, L.hitValues.z, __uint_as_float(L.px | (L.lrow << 16))));
 }
 
 // a path whose next ray is the closest-hit ray (rgen:64-75) -> slot i of stream C
 VKRT_DEV void storeClosest(const WfBuffers& B, int parity, unsigned i, const LaneState& L)
 {
-  wfStore(&plane(B, parity, WF_C, WF_R0)[i], make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, 10000.0f));
-  wfStore(&plane(B, parity, WF_C, WF_R1)[i], make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f));
+  wfStore(rec(B, parity, WF_C, WF_R0, i), make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, 10000.0f));
+  wfStore(rec(B, parity, WF_C, WF_R1, i), make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f));
   storeState(B, parity, WF_C, i, L, L.curWeight);
 }
 
@@ -130,12 +137,12 @@ VKRT_DEV void storeClosest(const WfBuffers& B, int parity, unsigned i, const Lan
 // or, with the closest-hit ray of the next segment riding along, of stream P
 VKRT_DEV void storeShadow(const WfBuffers& B, int parity, int type, unsigned i, const LaneState& L, f3 contrib, f3 nextWeight)
 {
-  wfStore(&plane(B, parity, type, WF_R0)[i], make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, L.prd.lightDist - 0.1f));
-  wfStore(&plane(B, parity, type, WF_R1)[i], make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, L.prd.lightDist));
+  wfStore(rec(B, parity, type, WF_R0, i), make_float4(L.prd.rayOrigin.x, L.prd.rayOrigin.y, L.prd.rayOrigin.z, L.prd.lightDist - 0.1f));
+  wfStore(rec(B, parity, type, WF_R1, i), make_float4(L.prd.shadowRayDir.x, L.prd.shadowRayDir.y, L.prd.shadowRayDir.z, L.prd.lightDist));
   if(type == WF_P)
-    wfStore(&plane(B, parity, type, WF_R2)[i], make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f));
+    wfStore(rec(B, parity, type, WF_R2, i), make_float4(L.prd.rayDirection.x, L.prd.rayDirection.y, L.prd.rayDirection.z, 0.0f));
   storeState(B, parity, type, i, L, nextWeight);
-  wfStore(&plane(B, parity, type, WF_S3)[i], make_float4(contrib.x, contrib.y, contrib.z, 0.0f));
+  wfStore(rec(B, parity, type, WF_S3, i), make_float4(contrib.x, contrib.y, contrib.z, 0.0f));
 }
 
 // Block-aggregated slot assignment in the next round's streams: ballot + popcount inside each wave, wave totals
@@ -216,9 +223,9 @@ enum { WF_K_CLOSEST_C = 0, WF_K_CLOSEST_P = 1, WF_K_SHADOW_S = 2, WF_K_SHADOW_P 
 VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int kind, unsigned qi, const RayHit& hit)
 {
   if(kind == WF_K_SHADOW_S)
-    wfStore(&plane(B, par, WF_S, WF_H0)[qi], make_float4(0.0f, 0.0f, 0.0f, __int_as_float(hit.slot >= 0 ? 0 : -1)));
+    wfStore(rec(B, par, WF_S, WF_H0, qi), make_float4(0.0f, 0.0f, 0.0f, __int_as_float(hit.slot >= 0 ? 0 : -1)));
   else if(kind == WF_K_SHADOW_P)
-    ((float*)&plane(B, par, WF_P, WF_H0)[qi])[0] = __int_as_float(hit.slot >= 0 ? 1 : 0);  // the closest-hit lane of the record owns .yzw
+    ((float*)rec(B, par, WF_P, WF_H0, qi))[0] = __int_as_float(hit.slot >= 0 ? 1 : 0);  // the closest-hit lane of the record owns .yzw
   else
   {
     const int type = kind == WF_K_CLOSEST_C ? WF_C : WF_P;
@@ -229,11 +236,11 @@ VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int ki
       // travel with the hit, so the closest-hit shading starts at the vertex / material loads
       const uint4 ts = P.sc.triShade[hit.slot];
       inst = __float_as_int(P.sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
-      wfStore(&plane(B, par, type, WF_H1)[qi], make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w)));
+      wfStore(rec(B, par, type, WF_H1, qi), make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w)));
     }
-    float* h = (float*)&plane(B, par, type, WF_H0)[qi];
+    float* h = (float*)rec(B, par, type, WF_H0, qi);
     if(type == WF_C)
-      wfStore(&plane(B, par, WF_C, WF_H0)[qi], make_float4(hit.t, hit.u, hit.v, __int_as_float(inst)));
+      wfStore(rec(B, par, WF_C, WF_H0, qi), make_float4(hit.t, hit.u, hit.v, __int_as_float(inst)));
     else
     {
       h[1] = hit.u; h[2] = hit.v; h[3] = __int_as_float(inst);
@@ -276,15 +283,15 @@ void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
   float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
   if(valid)
   {
-    r0 = wfLoad(&plane(B, par, type, WF_R0)[qi]);
-    r1 = wfLoad(&plane(B, par, type, kind == WF_K_CLOSEST_P ? WF_R2 : WF_R1)[qi]);
+    r0 = wfLoad(rec(B, par, type, WF_R0, qi));
+    r1 = wfLoad(rec(B, par, type, kind == WF_K_CLOSEST_P ? WF_R2 : WF_R1, qi));
     if(kind == WF_K_CLOSEST_P)
       r0.w = 10000.0f;
   }
   // any-hit stage: the payload's seed when the ray is traced (S0.w: after the shading that produced the ray, raytrace.rgen:64-97)
   uint32_t raySeed = 0u;
   if((TM & VKRT_TM_DISSOLVE) && valid)
-    raySeed = __float_as_uint(wfLoad(&plane(B, par, type, WF_S0)[qi]).w);
+    raySeed = __float_as_uint(wfLoad(rec(B, par, type, WF_S0, qi)).w);
   TravCount tc;
   __shared__ int shareLds[VKRT_SHARE_LDS_WORDS];
   RayHit hit;
@@ -378,35 +385,41 @@ VKRT_DEV bool advanceSegmentHybrid(const TraceParams& P, const HybridGi& G, Lane
 // measured in round 2: bit-identical images, ~30 % fewer VALU instructions, no change in kernel time (5.94 vs 5.91 ms per
 // 4-spp frame): the stage is bound by its stream traffic to HBM and the latency of its gathers, not by issue.  Removed again;
 // profiles/r02_experiments.md #52.)
+// LDS of a shade workgroup (one allocation for the kernel: the C and the pair instantiation of shadeHitBlock share it)
+struct ShadeLds
+{
+  float lut[512];
+  unsigned wsum[WF_TYPES * (WF_BLOCK / 64 + 1)];
+};
+
 template <bool PAIR, bool HYBRID>
-VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const HybridGi& G, const int par, const unsigned count, const unsigned block)
+VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const HybridGi& G, const int par, const unsigned count, const unsigned block, ShadeLds& lds)
 {
   const int type = PAIR ? WF_P : WF_C;
   const unsigned lane = lane_id();
   const unsigned qi = block * WF_BLOCK + threadIdx.x;
-  __shared__ float lut[512];
   ShadeStats st;
   st.hits = 0; st.diffuse = 0; st.taps = 0;
-  st.lut = ldsTexelLut(P.sc, lut);
-  __shared__ unsigned wsum[WF_TYPES * (WF_BLOCK / 64 + 1)];
+  st.lut = ldsTexelLut(P.sc, lds.lut);
+  unsigned* wsum = lds.wsum;
   int to = -1;
   LaneState L;
   f3 contrib = mk3(0.0f), nextWeight = mk3(0.0f);
   if(qi < count)
   {
     loadCommon(P, B, par, type, qi, L);
-    const float4 h = wfLoad(&plane(B, par, type, WF_H0)[qi]), t4 = wfLoad(&plane(B, par, type, WF_H1)[qi]);
-    const float4 rd = wfLoad(&plane(B, par, type, PAIR ? WF_R2 : WF_R1)[qi]);
+    const float4 h = wfLoad(rec(B, par, type, WF_H0, qi)), t4 = wfLoad(rec(B, par, type, WF_H1, qi));
+    const float4 rd = wfLoad(rec(B, par, type, PAIR ? WF_R2 : WF_R1, qi));
     L.prd.rayDirection = mk3(rd.x, rd.y, rd.z);  // direction of the closest-hit ray that was traced
     L.prd.rayOrigin = mk3(0.0f);                 // rchit / rmiss do not read it
     if(PAIR)
     {
       // finish segment k first (rgen:99-116): its shadow ray came back with this record.  S0 holds the weight after it;
       // the segment is never the last of its sample (emission rule below), so advanceSegment only accumulates and steps depth
-      const float4 s3 = wfLoad(&plane(B, par, WF_P, WF_S3)[qi]);
+      const float4 s3 = wfLoad(rec(B, par, WF_P, WF_S3, qi));
       const bool shadowHit = __float_as_int(h.x) != 0;
       if(HYBRID)
-        (void)advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? wfLoad(&plane(B, par, WF_P, WF_R1)[qi]).w : 0.0f);
+        (void)advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? wfLoad(rec(B, par, WF_P, WF_R1, qi)).w : 0.0f);
       else
         (void)advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
     }
@@ -444,22 +457,22 @@ VKRT_DEV void shadeHitBlock(const TraceParams& P, const WfBuffers& B, const Hybr
 
 // ---- shade, results of stream S: the last segment of a sample (rgen:99-120), next sample or pixel store (light; many waves) ----
 template <bool HYBRID>
-VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const HybridGi& G, const int par, const unsigned count, const unsigned block)
+VKRT_DEV void shadeShadowBlock(const TraceParams& P, const WfBuffers& B, const HybridGi& G, const int par, const unsigned count, const unsigned block, ShadeLds& lds)
 {
   const unsigned lane = lane_id();
   const unsigned qi = block * WF_BLOCK + threadIdx.x;
-  __shared__ unsigned wsum[WF_TYPES * (WF_BLOCK / 64 + 1)];
+  unsigned* wsum = lds.wsum;
   bool toClosest = false;
   LaneState L;
   if(qi < count)
   {
     loadCommon(P, B, par, WF_S, qi, L);  // S0 holds the weight after this segment
-    const float4 h = wfLoad(&plane(B, par, WF_S, WF_H0)[qi]), s3 = wfLoad(&plane(B, par, WF_S, WF_S3)[qi]);
+    const float4 h = wfLoad(rec(B, par, WF_S, WF_H0, qi)), s3 = wfLoad(rec(B, par, WF_S, WF_S3, qi));
     L.prd.rayOrigin = mk3(0.0f);     // the sample ends here: startSample sets the next ray, or the pixel is stored
     L.prd.rayDirection = mk3(0.0f);
     const bool shadowHit = __float_as_int(h.w) >= 0;
     if(HYBRID)
-      toClosest = advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? wfLoad(&plane(B, par, WF_S, WF_R1)[qi]).w : 0.0f);
+      toClosest = advanceSegmentHybrid(P, G, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight, L.prd.depth == 1u ? wfLoad(rec(B, par, WF_S, WF_R1, qi)).w : 0.0f);
     else
       toClosest = advanceSegment(P, L, shadowHit, mk3(s3.x, s3.y, s3.z), L.curWeight);
   }
@@ -477,13 +490,17 @@ VKRT_DEV void shadeRound(const TraceParams& P, const WfBuffers& B, const HybridG
   const unsigned cC = *countOf(B, par, WF_C), cS = *countOf(B, par, WF_S), cP = *countOf(B, par, WF_P);
   const unsigned nC = (cC + WF_BLOCK - 1) / WF_BLOCK, nP = (cP + WF_BLOCK - 1) / WF_BLOCK, nS = (cS + WF_BLOCK - 1) / WF_BLOCK;
   unsigned blk = blockIdx.x;
+  __shared__ ShadeLds lds;
   if(blk < nC)
-    shadeHitBlock<false, HYBRID>(P, B, G, par, cC, blk);
+    shadeHitBlock<false, HYBRID>(P, B, G, par, cC, blk, lds);
   else if((blk -= nC) < nP)
-    shadeHitBlock<true, HYBRID>(P, B, G, par, cP, blk);
+    shadeHitBlock<true, HYBRID>(P, B, G, par, cP, blk, lds);
   else if((blk -= nP) < nS)
-    shadeShadowBlock<HYBRID>(P, B, G, par, cS, blk);
+    shadeShadowBlock<HYBRID>(P, B, G, par, cS, blk, lds);
 }
+#ifdef VKRT_SHADE_WAVES
+__attribute__((amdgpu_waves_per_eu(VKRT_SHADE_WAVES)))
+#endif
 __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
 {
   const HybridGi none{};
