@@ -1,7 +1,8 @@
 """A slice of the randomised differential campaign (tools/fuzz_parity.py): random scenes, cameras, builders and options, the HIP
 path tracer and the hybrid passes against the CPU oracle, bit for bit.  The long runs are in profiles/r02_fuzz_parity.json
 (137 k cases) and profiles/r03_fuzz_parity.json (the round-3 options: watertight test, any-hit dissolve stage, dead-shadow-ray
-skipping; findings and fixes listed there); this keeps 120 fixed seeds and the recorded finding seeds in the driver's GPU pass."""
+skipping; findings and fixes listed there) and profiles/r04_fuzz_parity.json (round 4: triangle pre-splitting, frames through
+vkrt_pathtrace_frames); this keeps 120 fixed seeds and the recorded finding seeds in the driver's GPU pass."""
 import os
 import sys
 
@@ -56,6 +57,21 @@ def test_watertight_sliver_cases_of_the_round3_campaign(seed):
 
     info, problems = fuzz_parity.run_case(seed)
     assert info["opts"].get(abi.VKRT_OPT_WATERTIGHT) == 1
+    assert not problems, problems
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget", [100, 30])
+def test_presplit_needle_case_of_the_round4_campaign(budget):
+    """Seed 42002111 with triangle pre-splitting forced (round 4): a 790-unit sliver (corner of 1.4e-3 rad at v0) was cut into pieces
+    whose boxes hug the sliver; binary32 Moeller-Trumbore accepts a point beside it that the loop over all triangles finds and the
+    pieces' boxes pruned -- one GI ray of one pixel, tree-dependent.  Needles (tri_prep.h: slop > 0) are no longer split; the case
+    must match the oracle under its own draw of options (megakernel, BVH2, dead-shadow-ray skipping)."""
+    import fuzz_parity
+    from vkrt_amd import abi
+
+    info, problems = fuzz_parity.run_case(42002111, force_opts={abi.VKRT_OPT_SPLIT_BUDGET: budget})
+    assert info["opts"].get(abi.VKRT_OPT_SPLIT_BUDGET) == budget
     assert not problems, problems
 
 

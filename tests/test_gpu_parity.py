@@ -403,6 +403,10 @@ def test_bench_starts_its_own_ranks_on_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and (d["config"]["width"], d["config"]["height"]) == (640, 360)
     assert "launching" in p.stderr and "torch.distributed.run" in p.stderr
+    # round 4: the line carries the single-GPU rate of the SAME frame (rank 0 alone, untimed region) and the efficiency against it
+    c = d["config"]
+    assert c["same_frame_single_gpu_Mrays_s"] > 0 and abs(c["efficiency_vs_same_frame"] - d["value"] / (2 * c["same_frame_single_gpu_Mrays_s"])) < 1e-9
+    assert c["frames_per_call"] >= 1 and c["frames_in_flight"] >= 1
 
 
 def _coincident_layers_scene(layers=5, n=12):

@@ -23,9 +23,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("seed", type=int)
     ap.add_argument("--watertight", action="store_true")
+    ap.add_argument("--force-opt", action="append", default=[], metavar="ID=VALUE", help="execution options forced on top of the case's draw, as in fuzz_parity.py")
     a = ap.parse_args()
     from vkrt_amd import abi as _abi
-    force = {_abi.VKRT_OPT_WATERTIGHT: 1} if a.watertight else None
+    force = {int(k): int(v) for k, v in (x.split("=") for x in a.force_opt)}
+    if a.watertight:
+        force[_abi.VKRT_OPT_WATERTIGHT] = 1
+    force = force or None
 
     def replay_ray(S, r2, k, o, d, tmin, tmax, anyh):
         orc, r = S["oracle"], S["renderer"]
@@ -62,17 +66,19 @@ def main():
         other_opts[abi.VKRT_OPT_BVH_LAYOUT] = 1 if S["opts"].get(abi.VKRT_OPT_BVH_LAYOUT, 1) == 0 else 0
         other_opts.pop(abi.VKRT_OPT_MODE, None)
         r2 = Renderer(S["flat"], device=0, build=S["kind"], options=other_opts)
-        pc = make_push_constants(samples=S["spp"], depth=S["depth"], frame=S["first_frame"], lights_count=S["L"])
         for y, x in list(zip(*np.nonzero(diff)))[:4]:
             print(f"pixel ({x},{y}): gpu {got[y, x]} brute {ref[y, x]}")
-            _, log = orc.pixel_log(pc, cam, W, H, int(x), int(y), seed=S["seed"] + S["first_frame"], flags=S["flags"], use_bvh=False)
-            k = 0
-            for rec in log:
-                if rec[0] in (-2.0, -3.0):
-                    anyh = rec[0] == -3.0
-                    if not replay_ray(S, r2, k, rec[1:4].copy(), rec[4:7].copy(), 0.001, float(rec[7]), anyh):
-                        break
-                    k += 1
+            for f in range(S["first_frame"], S["first_frame"] + S["frames"]):  # every frame of the sequence (frames > 0 jitter the camera ray)
+                pc = make_push_constants(samples=S["spp"], depth=S["depth"], frame=f, lights_count=S["L"])
+                _, log = orc.pixel_log(pc, cam, W, H, int(x), int(y), seed=S["seed"] + f, flags=S["flags"], use_bvh=False)
+                print(f" frame {f}:")
+                k = 0
+                for rec in log:
+                    if rec[0] in (-2.0, -3.0):
+                        anyh = rec[0] == -3.0
+                        if not replay_ray(S, r2, k, rec[1:4].copy(), rec[4:7].copy(), 0.001, float(rec[7]), anyh):
+                            break
+                        k += 1
         r2.close()
 
     def hook(S):

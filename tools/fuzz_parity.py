@@ -198,6 +198,8 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
     elif edge < 0.04: depth = 0
     elif edge < 0.06: L = 0          # the light pick then always reads light 0 (int(rnd * 0))
     elif edge < 0.08: W, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    if frames_call and W * H * max(spp, 1) * max(depth, 1) * frames > 3_000_000:  # (the scalar oracle renders every frame: keep a long sequence of a large, deep case short)
+        frames = 2
     first_frame = int(rng.integers(0, 3)) if rng.random() < 0.2 else 0  # start a sequence at frame > 0 (jittered from the first launch on)
     flags = abi.VKRT_TRACE_SEED_INDEX_ROW_MAJOR if rng.random() < 0.5 else 0
     info = dict(seed=seed, tris=flat.instanced_triangle_count, size=(W, H), kind=kind, opts={int(k): int(v) for k, v in opts.items()}, spp=spp, depth=depth, frames=frames)
@@ -352,6 +354,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None, help="replay one case")
+    ap.add_argument("--start", type=int, default=0, help="first case number of the campaign (seed = --seed * 1000003 + number)")
+    ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = run for --seconds)")
+    ap.add_argument("--echo", action="store_true", help="print every seed before its case runs, and the Python stack of a case that takes longer than 60 s")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"))
     ap.add_argument("--force-opt", action="append", default=[], metavar="ID=VALUE", help="apply this execution option to every case (e.g. 10=1: the watertight test)")
     a = ap.parse_args()
@@ -361,16 +366,23 @@ def main():
         return 0
     t0 = time.time()
     n = bad = 0
+    first = a.start
     failures = []
-    tris = rays = tree_notes = needle_notes = needle_notes_wt = n_wt = n_dissolve = n_skip = 0
+    tris = rays = tree_notes = needle_notes = needle_notes_wt = n_wt = n_dissolve = n_skip = n_split = n_frames_call = 0
     lit = 0.0
-    while time.time() - t0 < a.seconds:
-        seed = a.seed * 1000003 + n
+    while time.time() - t0 < a.seconds and (a.count == 0 or n < a.count):
+        seed = a.seed * 1000003 + first + n
+        if a.echo:
+            import faulthandler
+            print(f"case {first + n} seed {seed}", flush=True)
+            faulthandler.dump_traceback_later(60, exit=False)
         try:
             info, problems = run_case(seed, force_opts=force)
         except Exception as e:  # an API error is a finding too
             info, problems = dict(seed=seed), [("exception", repr(e), 0)]
             print(json.dumps({"seed": seed, "exception": repr(e)}), flush=True)
+        if a.echo:
+            faulthandler.cancel_dump_traceback_later()
         n += 1
         tris += info.get("tris", 0)
         tree_notes += 1 if info.get("oracle_tree_differs_from_brute_force") else 0
@@ -379,6 +391,8 @@ def main():
         n_wt += 1 if o.get(abi.VKRT_OPT_WATERTIGHT) else 0
         n_dissolve += 1 if o.get(abi.VKRT_OPT_ANYHIT_DISSOLVE) else 0
         n_skip += 1 if o.get(abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS) else 0
+        n_split += 1 if o.get(abi.VKRT_OPT_SPLIT_BUDGET) else 0
+        n_frames_call += 1 if abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT in o else 0
         needle_notes_wt += 1 if (info.get("needle_limit_pixels") and o.get(abi.VKRT_OPT_WATERTIGHT)) else 0
         rays += info.get("rays", 0)
         lit += info.get("lit", 0.0)
@@ -390,7 +404,8 @@ def main():
     out = {"forced_options": force, "cases": n, "with_findings": bad, "seconds": round(time.time() - t0, 1), "triangles_total": tris, "rays_total": rays, "mean_lit_pixel_fraction": round(lit / max(n, 1), 3),
            "cases_where_only_the_oracle_tree_walk_differed_from_brute_force": tree_notes,
            "cases_at_the_needle_limit": needle_notes, "cases_at_the_needle_limit_with_the_watertight_test": needle_notes_wt,
-           "cases_with_the_watertight_test": n_wt, "cases_with_the_anyhit_dissolve_stage": n_dissolve, "cases_skipping_dead_shadow_rays": n_skip, "first_seed": a.seed * 1000003, "failures": failures[:50]}
+           "cases_with_the_watertight_test": n_wt, "cases_with_the_anyhit_dissolve_stage": n_dissolve, "cases_skipping_dead_shadow_rays": n_skip,
+           "cases_with_triangle_presplitting": n_split, "cases_through_vkrt_pathtrace_frames": n_frames_call, "first_seed": a.seed * 1000003, "failures": failures[:50]}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1, default=str)
     print(json.dumps({k: v for k, v in out.items() if k != "failures"}))

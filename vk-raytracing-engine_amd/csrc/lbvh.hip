@@ -364,8 +364,8 @@ __global__ void k_depth(unsigned kLeaf, int n, const int2* range, const int* par
 //                           halves in proportion to the longest sides of their boxes.
 // Only references multiply: every piece points at the ORIGINAL 48-byte record (copied into each slot by k_pack), the hit test, the
 // triangle id of the tie rule and every pixel stay what they were.  A piece's box = bounds of (triangle cut by the plane), clamped
-// to the box of the piece it came from -- conservative in floating point (the cut points are padded by 8 ulp of their coordinates,
-// the needle slop of tri_prep.h is added to every piece) and never larger than the triangle's own box.
+// to the box of the piece it came from -- conservative in floating point (the cut points are padded by 8 ulp of their coordinates)
+// and never larger than the triangle's own box.  Needle triangles (tri_prep.h: slop > 0) are not split (k_split_priority).
 #define VKRT_SPLIT_GRID_BITS 21          // the Morton grid of k_morton
 #define VKRT_SPLIT_MAX_PER_TRI 255u
 #define VKRT_SPLIT_STACK 16
@@ -614,7 +614,11 @@ __global__ void k_split_priority(unsigned T, const float4* __restrict__ triU, co
   const SplitGrid G = loadSplitGrid(sceneBounds);
   SplitTri t;
   loadSplitTri(triU, triBox, g, watertight, t);
-  prio[g] = splitPriority(G, t);
+  // Needles (corner at v0 narrower than ~7 degrees: tri_prep.h) stay whole.  binary32 Moeller-Trumbore accepts points well outside such
+  // a triangle; the slop of tri_prep.h is an ESTIMATE of that reach, and around a whole needle -- a long diagonal box -- nothing ever
+  // depends on it being tight, while the boxes of a needle's pieces hug the sliver and do: campaign seed 42002111 (a 790-unit sliver,
+  // 1.4e-3 rad) lost a hit that the loop over all triangles finds.  The result must stay a property of the triangle set.
+  prio[g] = t.slop > 0.0f ? 0.0f : splitPriority(G, t);
 }
 
 // D with sum_t min(floor(D p_t), cap) <= budget, as large as 24 bisection steps find it (one workgroup; sums in a fixed order)
