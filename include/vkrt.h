@@ -210,7 +210,9 @@ enum vkrt_option {
                                    heuristic only: bit 1 = always the FARTHEST pending child first; bit 2 = farthest first for rays that end outside
                                    the bounds of the scene (a shadow ray towards a light outside the building is stopped by the building's shell,
                                    the last thing a front-to-back walk reaches), front to back otherwise; bit 3 = automatic: like bit 2 unless the
-                                   scene has room-sized triangles, which a front-to-back walk meets at once.  Default 9 = bits 0 and 3 [build];
+                                   scene has room-sized triangles, which a front-to-back walk meets at once.  Bit 4 (round 4): lanes that have no node
+                                   work to give but hold two or more pending triangles (a ray grazing a plane of thin strips leaves a node test
+                                   with up to 24) give half of them to an idle lane.  Default 25 = bits 0, 3 and 4 [build];
                                    env VKRT_WF_SHARE_FLAGS */
   VKRT_OPT_GBUFFER_MIPS    = 9, /* NOT a scheduling knob: 1 (default) = vkrt_gbuffer_raycast samples textures like the fragment shader it replaces
                                    (implicit LOD over the mip chain, anisotropy 4; hello_vulkan.cpp:448-454, :499), 0 = LOD 0; env VKRT_GBUFFER_MIPS */

@@ -770,7 +770,7 @@ def test_anyhit_child_order_is_resolved_per_scene(cornell_flat):
             r = Renderer(scene, device=0, build="ploc", options={} if flags is None else {abi.VKRT_OPT_WF_SHARE_FLAGS: flags})
             got[name, flags] = r.get_option(abi.VKRT_INFO_ANYHIT_ORDER)
             if flags is None:
-                assert r.get_option(abi.VKRT_OPT_WF_SHARE_FLAGS) == 9
+                assert r.get_option(abi.VKRT_OPT_WF_SHARE_FLAGS) == 25
                 with pytest.raises(VkrtError):
                     r.set_option(abi.VKRT_INFO_ANYHIT_ORDER, 2)
             r.close()

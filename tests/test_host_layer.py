@@ -213,6 +213,14 @@ def test_config_json_schema():
     assert (c["samples"], c["depth"], c["frames"]) == (1, 3, 1)  # reference defaults hello_vulkan.cpp:911-912
     c = host_py.parse_config(json.dumps({"scenes": ["a.gltf"], "scene": 0, "vsync": True, "width": 64, "height": 32, "samples": 16, "depth": 8, "frames": 4}))
     assert (c["samples"], c["depth"], c["frames"], c["vsync"]) == (16, 8, 4, 1)
+    # round 4: "framesPerCall" (frames handed to the library per call) and the tri-state library options: a key config.json does not
+    # name stays -1 = "leave what vkrt_scene_create read from the environment", a named one is 0 / 1
+    assert (c["framesPerCall"], c["watertight"], c["anyHitDissolve"], c["skipDeadShadowRays"]) == (1, -1, -1, -1)
+    c = host_py.parse_config(json.dumps({"scenes": ["a.gltf"], "scene": 0, "vsync": True, "width": 64, "height": 32, "frames": 12, "framesPerCall": 6,
+                                         "watertight": False, "skipDeadShadowRays": True}))
+    assert (c["framesPerCall"], c["watertight"], c["anyHitDissolve"], c["skipDeadShadowRays"]) == (6, 0, -1, 1)
+    with pytest.raises(ValueError):
+        host_py.parse_config(json.dumps({"scenes": ["a.gltf"], "scene": 0, "vsync": True, "width": 64, "height": 32, "framesPerCall": 0}))
     with pytest.raises(ValueError):
         host_py.parse_config(json.dumps({"scenes": ["a.gltf"], "scene": 0, "vsync": True, "width": 64}))  # missing key
     with pytest.raises(ValueError):

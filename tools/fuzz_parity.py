@@ -182,6 +182,7 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
         for m in flat.materials:
             if rng3.random() < 0.6:
                 m["pbrBaseColorFactor"][3] = float(rng3.choice([0.0, 0.05, 0.5, 0.95, float(rng3.random())]))
+    if abi.VKRT_OPT_WF_SHARE_FLAGS in opts and rng4.random() < 0.5: opts[abi.VKRT_OPT_WF_SHARE_FLAGS] |= 16  # triangle-group donation with the drawn rules (the default has it on)
     if rng4.random() < 0.35: opts[abi.VKRT_OPT_SPLIT_BUDGET] = int(rng4.choice([10, 30, 100]))  # several references per large triangle (device builders)
     frames_call = rng4.random() < 0.3  # the frames of the sequence in ONE vkrt_pathtrace_frames call, with whatever lanes the draw gives
     if frames_call:

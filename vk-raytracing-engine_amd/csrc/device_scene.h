@@ -97,7 +97,8 @@ struct DevScene
   uint32_t sharePeriodMask;   // work sharing is attempted on steps with (step & mask) == mask (0 = every step)
   uint32_t shareMinIdle;      // wide8, wavefront mode: idle lanes of a wave take over pending subtrees of busy lanes once this many are idle (0 = off)
   uint32_t gbufferMips;       // hybrid G-buffer: 1 = implicit-LOD texture() as in a fragment shader (trilinear + 4x anisotropy), 0 = LOD 0
-  uint32_t shareFlags;        // bit 0: lanes whose stack is empty also donate the farthest pending child of their current group
+  uint32_t shareFlags;        // bit 0: lanes whose stack is empty also donate the farthest pending child of their current group; bits 1, 2: order of
+                              // any-hit walks (traverse.h); bit 4: lanes with nothing else to give donate half of their pending triangles
   uint32_t watertight;        // 1: triangle records hold (p0, p1, p2) and the kernels run the watertight test (VKRT_OPT_WATERTIGHT)
   float sceneLo[3], sceneHi[3];  // world-space bounds of the instanced geometry (conservative; read by the any-hit order heuristic only)
   uint32_t dissolve;          // 1: any-hit alpha / dissolve stage (VKRT_OPT_ANYHIT_DISSOLVE): bit 31 of a record's id word flags a non-opaque triangle

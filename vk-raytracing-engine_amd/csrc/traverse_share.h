@@ -81,15 +81,25 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
     if((iter & sc.sharePeriodMask) == sc.sharePeriodMask && (unsigned)__popcll(~busyMask) >= shareMin)
     {
       // donors: lanes with a pending group on their stack give the oldest one (largest, farthest subtree); with shareFlags bit 0
-      // a lane whose stack is empty but whose current group still has two or more pending children gives the farthest of them
+      // a lane whose stack is empty but whose current group still has two or more pending children gives the farthest of them;
+      // with shareFlags bit 4 (round 4) a lane that has no node work to give gives TRIANGLES: a parked triangle group whole, or the
+      // upper half (by position in the node's triangle block) of two or more pending triangles.  A ray grazing a plane of thin strips
+      // comes out of ONE node test with up to 24 triangles to test, one per step, while the rest of the wave has long finished: on
+      // Sponza-like drapery half of all steps were such triangle-only steps at 16 % lane efficiency (profiles/r04_experiments.md
+      // #113, #116).  (A second matching round, so that lanes giving node work can give triangles in the same step, costs more per
+      // step than it saves: -2.7 % on the uniform scene, #116b.)
       const bool giveStack = busy && sp - sb >= 1;
       const bool giveChild = (sc.shareFlags & 1u) != 0u && busy && !giveStack && (G.y & 0xff000000u & ((G.y & 0xff000000u) - 1u)) != 0u;
-      const unsigned long long donorMask = __ballot(giveStack || giveChild), idleMask = ~busyMask;
+      const bool mayTris = (sc.shareFlags & 16u) != 0u && busy && !giveStack && !giveChild;
+      const bool giveParked = mayTris && nPost > 0;
+      const bool giveTris = mayTris && !giveParked && (T.y & (T.y - 1u)) != 0u;
+      const bool wants = giveStack || giveChild || giveParked || giveTris;
+      const unsigned long long donorMask = __ballot(wants), idleMask = ~busyMask;
       if(donorMask != 0ull)
       {
         const unsigned n = min((unsigned)__popcll(donorMask), (unsigned)__popcll(idleMask));
         const unsigned giveRank = (unsigned)__popcll(donorMask & below), takeRank = (unsigned)__popcll(idleMask & below);
-        const bool gives = (giveStack || giveChild) && giveRank < n;
+        const bool gives = wants && giveRank < n;
         const bool takes = !busy && takeRank < n;
         uint2 e = make_uint2(0u, 0u);
         if(gives)
@@ -99,13 +109,27 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
             e = stk[sb * stride];
             sb++;
           }
-          else
+          else if(giveChild)
           {
             const unsigned top = G.y & 0xff000000u;
             // the child this lane would visit LAST: the lowest pending bit in front-to-back order, the highest with farFirst
             const unsigned low = farFirst ? (0x80000000u >> (unsigned)__clz((int)top)) : (top & (0u - top));
             e = make_uint2(G.x, low | (G.y & 0xffu));
             G.y &= ~low;
+          }
+          else if(giveParked)
+          {
+            e = stk[(cap - nPost) * stride];
+            e.x |= 0x80000000u;  // bit 31 of the base marks the entry as a triangle group
+            nPost--;
+          }
+          else
+          {
+            // the triangles above the middle of the span of pending positions
+            const unsigned lo = (unsigned)__ffs((int)T.y) - 1u, hi = 31u - (unsigned)__clz((int)T.y);
+            const unsigned upper = T.y & ~((1u << ((lo + hi + 1u) >> 1)) - 1u);
+            e = make_uint2(T.x | 0x80000000u, upper);
+            T.y &= ~upper;
           }
           res.donor[giveRank] = lane;  // r-th donor feeds the r-th idle lane
         }
@@ -129,8 +153,16 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           farFirst = ANYHIT && anyhit_far_first(sc, o, d, tmax);
           px = !(id.x < 0.0f); py = !(id.y < 0.0f); pz = !(id.z < 0.0f);
           octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
-          G = make_uint2(ex, ey);
-          T = make_uint2(0u, 0u);
+          if(ex & 0x80000000u)  // a triangle group of the donor's ray: nothing to walk, only to test
+          {
+            G = make_uint2(0u, 0u);
+            T = make_uint2(ex & 0x7fffffffu, ey);
+          }
+          else
+          {
+            G = make_uint2(ex, ey);
+            T = make_uint2(0u, 0u);
+          }
           sp = 0; sb = 0; nPost = 0;
           owner = ow;
           steps = sc.stepLimit;
@@ -248,6 +280,8 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           triStep = (unsigned)__popcll(__ballot(T.y != 0u)) >= sc.triThreshold || __ballot((G.y & 0xff000000u) != 0u) == 0ull;
         if(T.y != 0u && triStep && !(ANYHIT && found))
           testOne();
+        // (testing two or three triangles per lane in steps where no lane of the wave has node work left -- all loop overhead around one
+        //  test -- did not pay: 4110 -> 4082 / 4078 Mrays/s on the strip scene, profiles/r04_experiments.md #116c)
         if(ANYHIT && found)
           finished = true;
         else if((G.y & 0xff000000u) == 0u && T.y == 0u && nPost == 0)

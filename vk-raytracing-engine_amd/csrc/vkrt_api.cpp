@@ -23,7 +23,7 @@
 
 #define VKRT_TRI_THRESHOLD_DEFAULT 1
 #define VKRT_WF_SHARE_DEFAULT 16
-#define VKRT_WF_SHARE_FLAGS_DEFAULT 9
+#define VKRT_WF_SHARE_FLAGS_DEFAULT 25
 #define VKRT_WF_FRAMES_IN_FLIGHT_DEFAULT 3
 #define VKRT_SPLIT_BUDGET_DEFAULT 0
 #include "lbvh.h"
@@ -208,7 +208,7 @@ int clampOption(int option, int v)
     case VKRT_OPT_WF_SHARE: return std::max(0, std::min(64, v));
     case VKRT_OPT_TRI_THRESHOLD: return std::max(0, std::min(65, v));
     case VKRT_OPT_WF_SHARE_PERIOD: return std::max(0, std::min(255, v));
-    case VKRT_OPT_WF_SHARE_FLAGS: return v & 15;
+    case VKRT_OPT_WF_SHARE_FLAGS: return v & 31;
     case VKRT_OPT_GBUFFER_MIPS: case VKRT_OPT_WATERTIGHT: case VKRT_OPT_SKIP_DEAD_SHADOW_RAYS: case VKRT_OPT_ANYHIT_DISSOLVE: return v ? 1 : 0;
   }
   return v;
@@ -886,7 +886,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     // work sharing inside a traversal wave (traverse_share.h): minimum number of idle lanes before they take over subtrees
     s->dev.shareMinIdle = (uint32_t)s->opt[VKRT_OPT_WF_SHARE];
     s->dev.sharePeriodMask = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_PERIOD];
-    s->dev.shareFlags |= (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 1u;
+    s->dev.shareFlags |= (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 17u;  // bit 0: child donation, bit 4: triangle-group donation
   }
   // LDS budget: stackCap * 256 lanes * 4 B must fit a workgroup (160 KiB per CU on gfx950)
   if((size_t)s->dev.stackCap * 256 * 4 > 64 * 1024)

@@ -66,7 +66,8 @@ void vkrt_host_global_uniforms(const float* eye, const float* center, const floa
   *out = makeGlobalUniforms(cam, width, height);
 }
 
-// parse config text; out: [scene, vsync, width, height, samples, depth, frames, seed, nscenes]; path of the selected scene
+// parse config text; out: [scene, vsync, width, height, samples, depth, frames, seed, nscenes, framesPerCall, watertight, anyHitDissolve,
+// skipDeadShadowRays] (the three library options: -1 = key absent); path of the selected scene
 int vkrt_host_parse_config(const char* text, int* out, char* scenePath, int cap)
 {
   try
@@ -74,6 +75,7 @@ int vkrt_host_parse_config(const char* text, int* out, char* scenePath, int cap)
     const AppConfig c = parseConfig(text);
     out[0] = c.scene; out[1] = c.vsync; out[2] = c.width; out[3] = c.height; out[4] = c.samples; out[5] = c.depth;
     out[6] = c.frames; out[7] = c.seed; out[8] = (int)c.scenes.size();
+    out[9] = c.framesPerCall; out[10] = c.watertight; out[11] = c.anyHitDissolve; out[12] = c.skipDeadShadowRays;
     strncpy(scenePath, c.scenePath().c_str(), (size_t)cap - 1);
     scenePath[cap - 1] = 0;
     return 0;

@@ -108,12 +108,13 @@ def global_uniforms(eye=(0, 0, 15), center=(0, 0, 0), up=(0, 1, 0), fov=60.0, wi
 
 
 def parse_config(text):
-    out = np.zeros(9, np.int32)
+    out = np.zeros(13, np.int32)
     path = C.create_string_buffer(1024)
     rc = lib().vkrt_host_parse_config(text.encode(), out.ctypes.data, path, 1024)
     if rc != 0:
         raise ValueError(lib().vkrt_host_last_error().decode())
-    keys = ["scene", "vsync", "width", "height", "samples", "depth", "frames", "seed", "nscenes"]
+    keys = ["scene", "vsync", "width", "height", "samples", "depth", "frames", "seed", "nscenes", "framesPerCall", "watertight", "anyHitDissolve",
+            "skipDeadShadowRays"]
     d = dict(zip(keys, (int(x) for x in out)))
     d["scene_path"] = path.value.decode()
     return d
