@@ -107,11 +107,17 @@ struct DevScene
 // a traversal could not keep a pending subtree (stack full) or ran into the step bound: the result may be wrong -> make it visible
 #define VKRT_TRAV_FAULT(sc) atomicAdd((sc).faults, 1ull)
 
+#ifndef VKRT_W8_MAX_POSTPONED
+#define VKRT_W8_MAX_POSTPONED 8  // parked triangle groups per lane (traverse_wide.h, traverse_share.h), held in the free top end of its stack column
+#endif
+#ifndef VKRT_W8_POSTPONE_ROOM
+#define VKRT_W8_POSTPONE_ROOM 0  // entries of the column reserved for them on top of the node stack's own depth (vkrt_api.cpp); groups parked beyond
+                                 // these are tested out when a node push needs the slot (profiles/r04_experiments.md #117)
+#endif
+
 // Counter storage: 64 slots of 10 counters (padded to two 64-byte lines, order of vkrt_counters).  A workgroup
 // adds its block-reduced totals to slot (blockIdx % 64), so same-address atomic serialisation is
 // 64x lower than with one set of counters; vkrt_counters_read sums the slots.
-#define VKRT_W8_MAX_POSTPONED 2  // parked triangle groups per lane (traverse_wide.h)
-
 #define VKRT_COUNTER_SLOTS 64
 struct DevCounters
 {

@@ -234,6 +234,16 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           G.y &= ~(1u << bitIdx);
           if(G.y & 0xff000000u)
           {
+            if(__builtin_expect(sp + nPost >= cap && nPost > VKRT_W8_POSTPONE_ROOM, 0))
+            {
+              // a triangle group parked beyond its reserved room sits where this node group has to go: test it out now
+              const uint2 keep = T;
+              T = stk[(cap - nPost) * stride];
+              nPost--;
+              while(T.y != 0u && !(ANYHIT && found))
+                testOne();
+              T = keep;
+            }
             if(sp + nPost < cap)
             {
               stk[sp * stride] = G;

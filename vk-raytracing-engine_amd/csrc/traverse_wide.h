@@ -221,7 +221,8 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<TM>& S, float tmin, uint2* 
 // step has a few lanes with triangles and everyone else waits).  Here a lane keeps its pending triangle group T next
 // to its node group G; the wave tests triangles (one per lane per iteration) only when at least sc.triThreshold lanes
 // hold one, or when no lane has node work left.  A second group arriving while T is still pending is parked on the
-// top end of the lane's stack column (at most VKRT_W8_MAX_POSTPONED per lane, else tested at once).
+// top end of the lane's stack column (at most VKRT_W8_MAX_POSTPONED per lane, in whatever room the node stack leaves free beyond the
+// VKRT_W8_POSTPONE_ROOM entries reserved for them; a node push that needs the slot tests the newest parked group out; else tested at once).
 // The result does not depend on the order (closest = smallest t, ties -> smallest triangle id; any = exists).
 template <bool COUNT, bool ANYHIT, int TM>
 VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin, float tmax, uint2* stk, int stride, RayHit& hit, TravCount& tc,
@@ -293,6 +294,23 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
       G.y &= ~(1u << bitIdx);
       if(G.y & 0xff000000u)
       {
+        if(__builtin_expect(sp + nPost >= cap && nPost > VKRT_W8_POSTPONE_ROOM, 0))
+        {
+          // parked groups beyond the reserved entries live in free node-stack room: the node push needs the slot back, so the most
+          // recently parked group is tested out now
+          const uint2 keep = T;
+          T = stk[(cap - nPost) * stride];
+          nPost--;
+          while(T.y != 0u)
+            if(testOne())
+            {
+              done = true;
+              break;
+            }
+          if(done)
+            break;
+          T = keep;
+        }
         if(sp + nPost < cap)
         {
           stk[sp * stride] = G;

@@ -882,7 +882,7 @@ int vkrt_accel_build(vkrt_scene* s, uint32_t flags, void* hip_stream)
     // triangle postponing (traverse_wide.h): lanes with pending triangles before a wave tests them; 0 = immediate
     s->dev.triThreshold = (uint32_t)s->opt[VKRT_OPT_TRI_THRESHOLD];
     if(s->dev.triThreshold != 0u)
-      s->dev.stackCap += 2 * VKRT_W8_MAX_POSTPONED;  // room for parked triangle groups (uint2 entries)
+      s->dev.stackCap += 2 * VKRT_W8_POSTPONE_ROOM;  // room for parked triangle groups (uint2 entries)
     // work sharing inside a traversal wave (traverse_share.h): minimum number of idle lanes before they take over subtrees
     s->dev.shareMinIdle = (uint32_t)s->opt[VKRT_OPT_WF_SHARE];
     s->dev.sharePeriodMask = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_PERIOD];
