@@ -203,7 +203,8 @@ enum vkrt_option {
   VKRT_OPT_WF_SUBFRAMES    = 3, /* independent sub-frames of a launch on internal streams, 1..8 (default 3); env VKRT_WF_SUBFRAMES */
   VKRT_OPT_WF_TRAV_BLOCK   = 4, /* threads per traversal workgroup: 64 (default), 128, 256; env VKRT_WF_TRAV_BLOCK */
   VKRT_OPT_WF_SHARE        = 5, /* idle lanes of a traversal wave needed before they adopt subtrees, 0 = off (default 16) [build]; env VKRT_WF_SHARE */
-  VKRT_OPT_TRI_THRESHOLD   = 6, /* lanes with pending triangles before a wave tests them, 0 = test at once (default 1) [build]; env VKRT_TRI_THRESHOLD */
+  VKRT_OPT_TRI_THRESHOLD   = 6, /* lanes with pending triangles, per 64 lanes still walking, before a wave tests them; 1 = every step, 0 = test at once,
+                                   no parking (default 32) [build]; env VKRT_TRI_THRESHOLD */
   VKRT_OPT_WF_SHARE_PERIOD = 7, /* sharing attempted on steps with (step & mask) == mask (default 0 = every step) [build]; env VKRT_WF_SHARE_PERIOD */
   VKRT_OPT_WF_SHARE_FLAGS  = 8, /* bit 0: lanes with an empty stack also donate a pending child of their current group.  Bits 1-3: child order of
                                    any-hit (shadow / AO) walks -- "is anything in the way" has the same answer in any order, so this is a cost

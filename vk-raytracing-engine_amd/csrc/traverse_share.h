@@ -283,11 +283,14 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           T = stk[(cap - nPost) * stride];
           nPost--;
         }
-        // triangle step: with triThreshold > 1 the wave tests triangles only when that many of its walking lanes hold a pending
-        // group, or none of them has node work left (experiment #57; 1 = every iteration, the default)
+        // triangle step: with triThreshold > 1 the wave tests triangles only when that many of 64 walking lanes hold a pending group
+        // (the share of the lanes still busy, so that the thin tail of a wave is not left waiting for a count it cannot reach), or
+        // none of them has node work left.  1 = every iteration (experiment #57); default 32: with eight parked groups per lane the
+        // triangle step runs at 45 % instead of 29 % lane efficiency for 1.5 % more node visits (profiles/r04_experiments.md #118)
         bool triStep = true;
         if(sc.triThreshold > 1u)
-          triStep = (unsigned)__popcll(__ballot(T.y != 0u)) >= sc.triThreshold || __ballot((G.y & 0xff000000u) != 0u) == 0ull;
+          triStep = (unsigned)__popcll(__ballot(T.y != 0u)) * 64u >= sc.triThreshold * (unsigned)__popcll(busyMask) ||
+                    __ballot((G.y & 0xff000000u) != 0u) == 0ull;
         if(T.y != 0u && triStep && !(ANYHIT && found))
           testOne();
         // (testing two or three triangles per lane in steps where no lane of the wave has node work left -- all loop overhead around one

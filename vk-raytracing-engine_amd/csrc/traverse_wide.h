@@ -219,8 +219,8 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<TM>& S, float tmin, uint2* 
 // Measured on the 1080p atrium (profiles/r01_experiments.md #17): with the immediate `while(T.y)` loop above a node
 // step runs at ~47 % lane efficiency but a triangle step at ~7 % (0.35 triangles per node visit, so nearly every wave
 // step has a few lanes with triangles and everyone else waits).  Here a lane keeps its pending triangle group T next
-// to its node group G; the wave tests triangles (one per lane per iteration) only when at least sc.triThreshold lanes
-// hold one, or when no lane has node work left.  A second group arriving while T is still pending is parked on the
+// to its node group G; the wave tests triangles (one per lane per iteration) only when at least sc.triThreshold of 64 walking
+// lanes hold one, or when no lane has node work left.  A second group arriving while T is still pending is parked on the
 // top end of the lane's stack column (at most VKRT_W8_MAX_POSTPONED per lane, in whatever room the node stack leaves free beyond the
 // VKRT_W8_POSTPONE_ROOM entries reserved for them; a node push that needs the slot tests the newest parked group out; else tested at once).
 // The result does not depend on the order (closest = smallest t, ties -> smallest triangle id; any = exists).
@@ -358,7 +358,7 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
     }
     const bool hasT = T.y != 0u, hasG = (G.y & 0xff000000u) != 0u;
     const unsigned nT = (unsigned)__popcll(__ballot(hasT));
-    if(nT >= thresh || __ballot(hasG) == 0ull)
+    if(nT * 64u >= thresh * (unsigned)__popcll(__ballot(1)) || __ballot(hasG) == 0ull)  // thresh lanes of 64 still walking
     {
       if(hasT && testOne())
         break;

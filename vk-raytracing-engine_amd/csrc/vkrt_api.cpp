@@ -21,7 +21,7 @@
 #include "kernels.h"
 #include "wide_node.h"
 
-#define VKRT_TRI_THRESHOLD_DEFAULT 1
+#define VKRT_TRI_THRESHOLD_DEFAULT 32
 #define VKRT_WF_SHARE_DEFAULT 16
 #define VKRT_WF_SHARE_FLAGS_DEFAULT 25
 #define VKRT_WF_FRAMES_IN_FLIGHT_DEFAULT 3
