@@ -238,7 +238,7 @@ enum vkrt_option {
                                    dissolve; prd.seed itself is not advanced.  The result stays a property of the triangle set (any tree, any schedule);
                                    the oracle implements the same rule (orc_set_dissolve).  env VKRT_ANYHIT_DISSOLVE */
   VKRT_OPT_WF_FRAMES_IN_FLIGHT = 13, /* vkrt_pathtrace_frames: consecutive frames of a call rendered at the same time, 1..8 (default 3), each on
-                                   record streams of its own (864 B per pixel and frame in flight); their pixel values meet in the ordered blend at
+                                   record streams of its own (544 B per pixel and frame in flight); their pixel values meet in the ordered blend at
                                    the end of a frame, so the image is bit-identical for every value.  A call with frames in flight does not split
                                    its frames into sub-frames (option 3): few, large launches overlap best.  env VKRT_WF_FRAMES_IN_FLIGHT */
   VKRT_OPT_SPLIT_BUDGET    = 14, /* [build] NOT a pixel-changing knob: triangle pre-splitting in the device builders (VKRT_BUILD_PLOC_GPU /

@@ -152,7 +152,7 @@ struct TraceParams
 struct WfBuffers
 {
   unsigned* ctrl;       // stream counts [parity * 4 + type]; 64 words per lane
-  float4* planes;       // [group][parity * 3 + type][plane][capacity]
+  float4* planes;       // [group][parity][17 planes: 8 shared by the C and S streams, 9 of the pair stream][capacity] (wavefront.hip plane())
   float4* stage;        // [group][capacity]: pixel values of a frame in flight, shard-local image layout (groups > 1 only)
   uint32_t capacity;    // paths (pixels of the shard, rounded up to whole 8x8 tiles)
   uint32_t groups;      // frame groups the allocation holds

@@ -48,7 +48,7 @@
 #define VKRT_FLAG_COUNT_WORK 2u  // = VKRT_TRACE_COUNT_TRAVERSAL (include/vkrt.h)
 
 // ---- streams ---------------------------------------------------------------------------------------------------------
-// Six streams [parity][type], each WF_PLANES planes of `capacity` float4.  type 0 "C": the path's next ray is a closest-hit
+// Six streams [parity][type] of float4 planes with room for `capacity` records (storage: plane() below).  type 0 "C": the path's next ray is a closest-hit
 // ray; type 1 "S": a shadow ray, and the segment it belongs to is the last of its sample; type 2 "P" (pair): the shadow ray
 // of segment k and the closest-hit ray of segment k + 1, both from the hit point of segment k.
 //   plane 0  R0  ray origin.xyz, tmax of the first ray (C: 10000; S, P: lightDist - 0.1)      written by the producer
@@ -67,9 +67,15 @@
 enum { WF_R0 = 0, WF_R1, WF_R2, WF_H0, WF_H1, WF_S0, WF_S1, WF_S2, WF_S3 };
 enum { WF_C = 0, WF_S = 1, WF_P = 2 };
 
+// Storage.  A path is in exactly one stream, so the C and the S records of a round together never outnumber the paths: the two streams
+// share their planes -- C records fill a plane from the front, S records from the back (record i of S lives at capacity - 1 - i; a
+// wave still reads 1 KB contiguous) -- and neither of them has an R2 field.  17 planes per parity instead of 27: 544 B per path.
+#define WF_SLOTS_CS 8  // R0 R1 H0 H1 S0 S1 S2 S3 (C leaves S3 unused, S leaves H1 unused)
+#define WF_SLOTS (WF_SLOTS_CS + WF_PLANES)  // + the nine planes of the pair stream
 VKRT_DEV float4* plane(const WfBuffers& B, int parity, int type, int k)
 {
-  return B.planes + ((size_t)((parity * WF_TYPES + type) * WF_PLANES + k)) * B.capacity;
+  const int slot = type == WF_P ? WF_SLOTS_CS + k : (k > WF_R2 ? k - 1 : k);
+  return B.planes + ((size_t)(parity * WF_SLOTS + slot)) * B.capacity;
 }
 VKRT_DEV unsigned* countOf(const WfBuffers& B, int parity, int type) { return &B.ctrl[parity * 4 + type]; }
 // record i of a plane: the plane's base is uniform (kernel arguments, round parity, the workgroup's stream type) and the record's byte
@@ -77,7 +83,7 @@ VKRT_DEV unsigned* countOf(const WfBuffers& B, int parity, int type) { return &B
 // VGPR per access instead of two (the shade kernel holds a dozen of them at once)
 VKRT_DEV float4* rec(const WfBuffers& B, int parity, int type, int k, unsigned i)
 {
-  return (float4*)((char*)plane(B, parity, type, k) + (size_t)(i * 16u));
+  return (float4*)((char*)plane(B, parity, type, k) + (size_t)((type == WF_S ? B.capacity - 1u - i : i) * 16u));
 }
 
 // Stream records are written by one kernel and consumed by the next one or two (the traversal kernel reads the ray planes, the shade
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_blend(const TraceParams P, cons
 size_t vkrt_wf_state_bytes(uint32_t pathCapacity, int groups)
 {
   const size_t g = (size_t)std::max(groups, 1);
-  return g * pathCapacity * 2 * WF_TYPES * WF_PLANES * sizeof(float4) + (g > 1 ? g * pathCapacity * sizeof(float4) : 0) + WF_CTRL_BYTES;
+  return g * pathCapacity * 2 * WF_SLOTS * sizeof(float4) + (g > 1 ? g * pathCapacity * sizeof(float4) : 0) + WF_CTRL_BYTES;
 }
 
 void vkrt_wf_carve(void* base, uint32_t pathCapacity, int groups, WfBuffers* B)
@@ -616,7 +622,7 @@ void vkrt_wf_carve(void* base, uint32_t pathCapacity, int groups, WfBuffers* B)
   B->ctrl = (unsigned*)p;
   p += WF_CTRL_BYTES;
   B->planes = (float4*)p;
-  p += g * pathCapacity * 2 * WF_TYPES * WF_PLANES * sizeof(float4);
+  p += g * pathCapacity * 2 * WF_SLOTS * sizeof(float4);
   B->stage = g > 1 ? (float4*)p : nullptr;
   B->capacity = pathCapacity;
   B->groups = (uint32_t)g;
@@ -744,14 +750,14 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const
   hipStream_t laneStream[VKRT_WF_MAX_LANES];
   uint32_t tile0[VKRT_WF_MAX_LANES], tileN[VKRT_WF_MAX_LANES];
   WfBuffers Bq[VKRT_WF_MAX_LANES];
-  const size_t groupQuads = (size_t)2 * WF_TYPES * WF_PLANES * B.capacity;
+  const size_t groupQuads = (size_t)2 * WF_SLOTS * B.capacity;
   for(int q = 0; q < L; q++)
   {
     const int g = q / S, j = q % S;
     tile0[q] = (uint32_t)((uint64_t)P.tileCount * j / S);
     tileN[q] = (uint32_t)((uint64_t)P.tileCount * (j + 1) / S) - tile0[q];
     Bq[q].ctrl = B.ctrl + 64 * q;
-    Bq[q].planes = B.planes + (size_t)g * groupQuads + (size_t)2 * WF_TYPES * WF_PLANES * ((size_t)tile0[q] * 64u);
+    Bq[q].planes = B.planes + (size_t)g * groupQuads + (size_t)2 * WF_SLOTS * ((size_t)tile0[q] * 64u);
     Bq[q].stage = staged ? B.stage + (size_t)g * B.capacity : nullptr;
     Bq[q].capacity = tileN[q] * 64u;
     Bq[q].groups = 1;
@@ -858,7 +864,7 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const
 uint2* vkrt_wf_hybrid_tmp(const WfBuffers& B)
 {
   // the streams of parity 1 are first written by the shade step of round 0: until then their first plane is free
-  return (uint2*)(B.planes + (size_t)(1 * WF_TYPES + 0) * WF_PLANES * B.capacity);
+  return (uint2*)(B.planes + (size_t)(1 * WF_SLOTS + 0) * B.capacity);
 }
 
 hipError_t vkrt_launch_hybrid_gi(const TraceParams& P, const WfBuffers& B, const HybridGi& G, unsigned travBlock, hipStream_t stream)
