@@ -728,7 +728,11 @@ def test_scene_options_are_per_handle_and_do_not_change_pixels(atrium_small):
     cam = default_camera(W, H, **camkw)
     variants = [{}, {abi.VKRT_OPT_WF_SUBFRAMES: 1}, {abi.VKRT_OPT_WF_SUBFRAMES: 2}, {abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 0},
                 {abi.VKRT_OPT_WF_SHARE: 4, abi.VKRT_OPT_WF_SHARE_FLAGS: 1}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 2}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 5}, {abi.VKRT_OPT_WF_SHARE_FLAGS: 12}, {abi.VKRT_OPT_WF_TRAV_BLOCK: 256}, {abi.VKRT_OPT_BVH_LAYOUT: 0},
-                {abi.VKRT_OPT_TRI_THRESHOLD: 0, abi.VKRT_OPT_WF_SHARE: 0}, {abi.VKRT_OPT_MODE: 0}]
+                {abi.VKRT_OPT_TRI_THRESHOLD: 0, abi.VKRT_OPT_WF_SHARE: 0},
+                # triangle-step threshold (default 32 of 64 walking lanes): every step, never before the node work runs out, and the
+                # postponing walk without work sharing (parked groups are evicted by node pushes in both walks)
+                {abi.VKRT_OPT_TRI_THRESHOLD: 1}, {abi.VKRT_OPT_TRI_THRESHOLD: 65}, {abi.VKRT_OPT_TRI_THRESHOLD: 48, abi.VKRT_OPT_WF_SHARE: 0},
+                {abi.VKRT_OPT_MODE: 0}]
     rs = [Renderer(flat, device=0, build="sah", options=v) for v in variants]
     assert rs[1].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 1 and rs[0].get_option(abi.VKRT_OPT_WF_SUBFRAMES) == 3
     with pytest.raises(VkrtError):
