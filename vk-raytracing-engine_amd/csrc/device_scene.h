@@ -48,6 +48,19 @@ struct DevMaterial
   DevTexRef tex[4];
 };
 static_assert(sizeof(DevMaterial) == 128, "DevMaterial");
+// The hit shader's view of a material (shade.h closestHitFront): the factors raytrace.rchit reads and the four texture references
+// in 64 bytes = four aligned 16-byte loads per hit (DevMaterial: eight).
+//   f = (baseColor.xyz, metallic, roughness, emissive.xyz)   ref[2 k], ref[2 k + 1] = reference k (VKRT_TEXREF_*):
+//   dims = (width - 1) | used << 15 | (height - 1) << 16 | valid << 31   (used: the material's texture index is > -1; valid: it
+//          names an uploaded texture; an invalid reference has width = height = 1), sides up to 32768
+//   base = first record of the texture in the footprint pool (DevScene::texQuads), or its first texel when the scene has no such
+//          pool; | sRGB << 31
+struct DevShadeMaterial
+{
+  float f[8];
+  uint32_t ref[8];
+};
+static_assert(sizeof(DevShadeMaterial) == 64, "DevShadeMaterial");
 
 #define VKRT_MAX_MIPS 16
 struct DevTexture
@@ -75,6 +88,7 @@ struct DevScene
   const uint32_t* indices;
   const float4* vertexPN;     // VKRT_VERTEX_QUADS float4 per vertex (see above)
   const DevMaterial* materials;
+  const DevShadeMaterial* shadeMaterials;  // the same materials as the path tracer's hit shader reads them
   const GltfLight* lights;
   const DevInstance* instances;
   const DevTexture* textures;

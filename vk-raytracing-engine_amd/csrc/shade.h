@@ -370,16 +370,18 @@ VKRT_DEV void closestHitFront(const DevScene& sc, const RayHit& hit, const uint3
   const uint32_t i0 = ts.x, i1 = ts.y, i2 = ts.z, matIndex = ts.w;
   const f3 b = mk3(1.0f - hit.u - hit.v, hit.u, hit.v);  // rchit:68
 
-  const BufView vPN = bufView(sc.vertexPN), vMat = bufView(sc.materials), vInst = bufView(sc.instances);
+  const BufView vPN = bufView(sc.vertexPN), vMat = bufView(sc.shadeMaterials), vInst = bufView(sc.instances);
   const float4 a0 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i0), b0 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i0 + 16u), tq0 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i0 + 32u);
   const float4 a1 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i1), b1 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i1 + 16u), tq1 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i1 + 32u);
   const float4 a2 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i2), b2 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i2 + 16u), tq2 = bufLoad4(vPN, VKRT_VERTEX_BYTES * i2 + 32u);
-  // material: eight aligned 16-byte loads of the 128-byte record (factors + the four texture descriptors).  (Staging the material
-  // and instance tables in LDS per workgroup -- 14 ds_read_b128 instead of 14 lane-loads that nearly always hit L1 -- made the stage
-  // 9 % SLOWER: the copy costs more than those hot loads did; profiles/r04_experiments.md #115)
-  const uint32_t mo = 128u * matIndex;
-  const float4 m0 = bufLoad4(vMat, mo), m1 = bufLoad4(vMat, mo + 16u), m2 = bufLoad4(vMat, mo + 32u), m3 = bufLoad4(vMat, mo + 48u);
-  const float4 d0 = bufLoad4(vMat, mo + 64u), d1 = bufLoad4(vMat, mo + 80u), d2 = bufLoad4(vMat, mo + 96u), d3 = bufLoad4(vMat, mo + 112u);
+  // material: four aligned 16-byte loads of the 64-byte hit-shader record (DevShadeMaterial: the factors rchit reads + the four texture
+  // references; the 128-byte DevMaterial took eight).  (Staging the material and instance tables in LDS per workgroup -- ds_read_b128
+  // instead of lane-loads that nearly always hit L1 -- made the stage 9 % SLOWER: the copy costs more than those hot loads did;
+  // profiles/r04_experiments.md #115)
+  const uint32_t mo = 64u * matIndex;
+  const float4 m0 = bufLoad4(vMat, mo), m1 = bufLoad4(vMat, mo + 16u), ref01 = bufLoad4(vMat, mo + 32u), ref23 = bufLoad4(vMat, mo + 48u);
+  const uint32_t dimB = __float_as_uint(ref01.x), baseB = __float_as_uint(ref01.y), dimM = __float_as_uint(ref01.z), baseM = __float_as_uint(ref01.w);
+  const uint32_t dimN = __float_as_uint(ref23.x), baseN = __float_as_uint(ref23.y), dimE = __float_as_uint(ref23.z), baseE = __float_as_uint(ref23.w);
   DevInstance in;
   {
     const uint32_t io = 96u * instId;  // 96-byte record: six aligned 16-byte loads
@@ -390,12 +392,12 @@ VKRT_DEV void closestHitFront(const DevScene& sc, const RayHit& hit, const uint3
     in.w2o[0] = q3.x; in.w2o[1] = q3.y; in.w2o[2] = q3.z; in.w2o[3] = q3.w; in.w2o[4] = q4.x; in.w2o[5] = q4.y; in.w2o[6] = q4.z; in.w2o[7] = q4.w;
     in.w2o[8] = q5.x; in.primMesh = __float_as_int(q5.y); in.pad[0] = 0; in.pad[1] = 0;
   }
-  GltfPBRMaterial mat;
-  mat.pbrBaseColorFactor[0] = m0.x; mat.pbrBaseColorFactor[1] = m0.y; mat.pbrBaseColorFactor[2] = m0.z; mat.pbrBaseColorFactor[3] = m0.w;
-  mat.pbrBaseColorTexture = __float_as_int(m1.x); mat.metallicFactor = m1.y; mat.roughnessFactor = m1.z;
-  mat.metallicRoughnessTexture = __float_as_int(m1.w);
-  mat.normalTexture = __float_as_int(m2.x); mat.emissiveFactor[0] = m2.y; mat.emissiveFactor[1] = m2.z; mat.emissiveFactor[2] = m2.w;
-  mat.emissiveTexture = __float_as_int(m3.x);
+  GltfPBRMaterial mat;  // (the fields this shader reads; a texture index only matters as "> -1": bit 15 of the reference's first word)
+  mat.pbrBaseColorFactor[0] = m0.x; mat.pbrBaseColorFactor[1] = m0.y; mat.pbrBaseColorFactor[2] = m0.z; mat.pbrBaseColorFactor[3] = 1.0f;
+  mat.metallicFactor = m0.w; mat.roughnessFactor = m1.x;
+  mat.emissiveFactor[0] = m1.y; mat.emissiveFactor[1] = m1.z; mat.emissiveFactor[2] = m1.w;
+  mat.pbrBaseColorTexture = (dimB & 0x8000u) ? 0 : -1; mat.metallicRoughnessTexture = (dimM & 0x8000u) ? 0 : -1;
+  mat.normalTexture = (dimN & 0x8000u) ? 0 : -1; mat.emissiveTexture = (dimE & 0x8000u) ? 0 : -1;
   const float tu = (b0.z * b.x + b1.z * b.y) + b2.z * b.z;
   const float tv = (b0.w * b.x + b1.w * b.y) + b2.w * b.z;
 
@@ -407,30 +409,31 @@ VKRT_DEV void closestHitFront(const DevScene& sc, const RayHit& hit, const uint3
   const bool wantB = mat.pbrBaseColorTexture > -1, wantM = mat.metallicRoughnessTexture > -1;
   st.taps += (wantE ? 1u : 0u) + (wantN ? 1u : 0u) + (wantB ? 1u : 0u) + (wantM ? 1u : 0u);
   TexTap tE, tN, tB, tM;
-#define VKRT_FOOTPRINT(q, want, tap)                                                                                                   \
-  texFootprint(__float_as_uint(q.x), __float_as_uint(q.y) & 0xffffu, __float_as_uint(q.y) >> 16, (__float_as_uint(q.z) & 2u) != 0u,     \
-               (__float_as_uint(q.z) & 1u) != 0u, want, tu, tv, tap)
-  VKRT_FOOTPRINT(d3, wantE, tE);
-  VKRT_FOOTPRINT(d2, wantN, tN);
-  VKRT_FOOTPRINT(d0, wantB, tB);
-  VKRT_FOOTPRINT(d1, wantM, tM);
+  // (with a footprint pool the tap's texel number is relative to the texture: the pool's record number is added below)
+#define VKRT_FOOTPRINT(dim, base, want, tap)                                                                                           \
+  texFootprint(sc.texQuads ? 0u : ((base) & 0x7fffffffu), ((dim) & 0x7fffu) + 1u, (((dim) >> 16) & 0x7fffu) + 1u, ((base) >> 31) != 0u, \
+               ((dim) >> 31) != 0u, want, tu, tv, tap)
+  VKRT_FOOTPRINT(dimE, baseE, wantE, tE);
+  VKRT_FOOTPRINT(dimN, baseN, wantN, tN);
+  VKRT_FOOTPRINT(dimB, baseB, wantB, tB);
+  VKRT_FOOTPRINT(dimM, baseM, wantM, tM);
 #undef VKRT_FOOTPRINT
   uint32_t e00, e10, e01, e11, n00, n10, n01, n11, c00, c10, c01, c11, r00, r10, r01, r11;
   if(sc.texQuads)
   {
     // one 16-byte record per tap: the 2x2 footprint at (x0, y0) with the wrap already applied (DevScene::texQuads); the record
-    // number is the level-0 texel number of i00 moved from the texel pool's numbering to the footprint pool's
+    // number is the texture's first record + the level-0 texel number of i00 inside the texture
     const BufView quads = bufView(sc.texQuads);
-#define VKRT_QUAD(q, tap, want, a, b, c, d)                                                                                            \
+#define VKRT_QUAD(dim, base, tap, want, a, b, c, d)                                                                                    \
   {                                                                                                                                    \
-    const uint32_t rec_ = ((want) && (__float_as_uint(q.z) & 1u) != 0u) ? (tap.i00 - __float_as_uint(q.x)) + __float_as_uint(q.w) : 0u; \
+    const uint32_t rec_ = ((want) && ((dim) >> 31) != 0u) ? tap.i00 + ((base) & 0x7fffffffu) : 0u;                                        \
     const float4 v_ = bufLoad4(quads, 16u * rec_);                                                                                     \
     a = __float_as_uint(v_.x); b = __float_as_uint(v_.y); c = __float_as_uint(v_.z); d = __float_as_uint(v_.w);                        \
   }
-    VKRT_QUAD(d3, tE, wantE, e00, e10, e01, e11)
-    VKRT_QUAD(d2, tN, wantN, n00, n10, n01, n11)
-    VKRT_QUAD(d0, tB, wantB, c00, c10, c01, c11)
-    VKRT_QUAD(d1, tM, wantM, r00, r10, r01, r11)
+    VKRT_QUAD(dimE, baseE, tE, wantE, e00, e10, e01, e11)
+    VKRT_QUAD(dimN, baseN, tN, wantN, n00, n10, n01, n11)
+    VKRT_QUAD(dimB, baseB, tB, wantB, c00, c10, c01, c11)
+    VKRT_QUAD(dimM, baseM, tM, wantM, r00, r10, r01, r11)
 #undef VKRT_QUAD
   }
   else

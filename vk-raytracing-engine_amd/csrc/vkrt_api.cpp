@@ -448,10 +448,20 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
     pool.push_back(0xffffffffu);  // shading always issues its texel loads (to texel 0 when a material has no texture)
   // materials, with the descriptors of their textures folded in (DevMaterial)
   std::vector<DevMaterial> mats(d->material_count);
+  std::vector<DevShadeMaterial> shadeMats(d->material_count);
   for(uint32_t i = 0; i < d->material_count; i++)
   {
     memset(&mats[i], 0, sizeof(DevMaterial));
     mats[i].m = d->materials[i];
+    DevShadeMaterial& sm = shadeMats[i];
+    memset(&sm, 0, sizeof(sm));
+    for(int k = 0; k < 3; k++)
+    {
+      sm.f[k] = d->materials[i].pbrBaseColorFactor[k];
+      sm.f[5 + k] = d->materials[i].emissiveFactor[k];
+    }
+    sm.f[3] = d->materials[i].metallicFactor;
+    sm.f[4] = d->materials[i].roughnessFactor;
     s->materialAlpha.push_back(d->materials[i].pbrBaseColorFactor[3]);
     const int idx[4] = {mats[i].m.pbrBaseColorTexture, mats[i].m.metallicRoughnessTexture, mats[i].m.normalTexture, mats[i].m.emissiveTexture};
     for(int k = 0; k < 4; k++)
@@ -461,13 +471,20 @@ int vkrt_scene_create(const vkrt_scene_desc* d, int device, vkrt_scene** out)
       if(idx[k] >= 0 && (uint32_t)idx[k] < d->texture_count)
       {
         const DevTexture& t = table[(size_t)idx[k]];
-        if(t.width == 0u || t.height == 0u || t.width > 65535u || t.height > 65535u)
-          return bail(fail(VKRT_ERR_UNSUPPORTED, "texture %d is %ux%u (supported: 1..65535 per side)", idx[k], t.width, t.height));
+        if(t.width == 0u || t.height == 0u || t.width > 32768u || t.height > 32768u)
+          return bail(fail(VKRT_ERR_UNSUPPORTED, "texture %d is %ux%u (supported: 1..32768 per side)", idx[k], t.width, t.height));
         r = DevTexRef{t.offset, t.width | (t.height << 16), 1u | ((t.srgb & 1u) ? 2u : 0u), wantQuads ? quadFirst[(size_t)idx[k]] : 0u};
       }
+      // (the reference order of DevShadeMaterial is VKRT_TEXREF_*: BASE, MR, NORMAL, EMISSIVE = the order of idx[])
+      const uint32_t base = wantQuads ? r.quads : r.offset;
+      if(base >> 31)
+        return bail(fail(VKRT_ERR_UNSUPPORTED, "texture pool of 2^31 records and more is not supported"));
+      sm.ref[2 * k] = ((r.wh & 0xffffu) - 1u) | (idx[k] > -1 ? 1u << 15 : 0u) | (((r.wh >> 16) - 1u) << 16) | ((r.flags & 1u) << 31);
+      sm.ref[2 * k + 1] = base | ((r.flags & 2u) << 30);
     }
   }
   if((rc = upload(s, mats.data(), mats.size(), &D.materials)) != VKRT_OK) return bail(rc);
+  if((rc = upload(s, shadeMats.data(), shadeMats.size(), &D.shadeMaterials)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, table.data(), table.size(), &D.textures)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, mipTable.data(), mipTable.size(), &D.texMips)) != VKRT_OK) return bail(rc);
   if((rc = upload(s, pool.data(), pool.size(), &D.texels)) != VKRT_OK) return bail(rc);
