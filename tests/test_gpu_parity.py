@@ -613,7 +613,7 @@ def test_triangle_soup_ray_queries_equal_brute_force(kind):
 
 def test_non_power_of_two_and_degenerate_textures(atrium_small):
     """texture() addressing outside the fast path: sizes that are not powers of two (general modulo for REPEAT), 1x1 and
-    one-texel-wide textures (a dangling texture index is refused at scene creation).
+    one-texel-wide textures, sides of 32768 (a dangling texture index and a side of 32769 are refused at scene creation).
     Whole image, GPU against oracle, bit for bit; the hybrid G-buffer sampler (descriptor-table path) as well."""
     import copy
 
@@ -623,7 +623,7 @@ def test_non_power_of_two_and_degenerate_textures(atrium_small):
 
     flat0, info, camkw = atrium_small
     flat = copy.deepcopy(flat0)
-    shapes = [(100, 60), (1, 1), (3, 5), (257, 1), (1, 33), (96, 96), (50, 7), (640, 360)]
+    shapes = [(100, 60), (1, 1), (3, 5), (257, 1), (1, 33), (32768, 1), (50, 7), (3, 32768)]  # 32768: the largest side a texture reference holds
     for t, (w, h) in zip(flat.textures, shapes):
         src = t["rgba8"]
         ys = (np.arange(h) * src.shape[0] // max(h, 1)) % src.shape[0]
@@ -633,6 +633,10 @@ def test_non_power_of_two_and_degenerate_textures(atrium_small):
     bad.materials["emissiveTexture"][0] = 99  # the ABI refuses dangling texture indices (the loader maps undecodable images to 1x1 white)
     with pytest.raises(Exception, match="out of range"):
         Renderer(bad, device=0, build="sah")
+    wide = copy.deepcopy(flat)
+    wide.textures[0]["rgba8"] = np.zeros((1, 32769, 4), np.uint8)  # one texel more than DevShadeMaterial's 15-bit side field
+    with pytest.raises(Exception, match="32768"):
+        Renderer(wide, device=0, build="sah")
     W, H = 256, 144
     cam = default_camera(W, H, **camkw)
     orc = oracle_py.OracleScene(flat)
