@@ -40,15 +40,8 @@ struct f4 { float x, y, z, w; };
 
 // Gathers of the hit shader go through buffer descriptors (four SGPRs built from a kernel-argument pointer) with a 32-bit byte
 // offset per lane instead of a 64-bit flat address per lane: one VGPR per address instead of two.  The shader holds 16 texel
-// addresses + 8 record addresses at its register peak, so this is what takes it from 140 to under 128 VGPRs, i.e. from three to four
-// waves per SIMD without a spill (profiles/r04_experiments.md #114).  Every table is < 4 GiB (vkrt_scene_create refuses larger ones);
+// addresses + 8 record addresses at its register peak (profiles/r04_experiments.md #114).  Every table is < 4 GiB (vkrt_scene_create refuses larger ones);
 // the range check of the descriptor is left open (all ones): indices are validated at upload, as before.
-#if defined(VKRT_SHADE_FLAT_LOADS)
-struct BufView { const char* p; };
-VKRT_DEV BufView bufView(const void* p) { return BufView{(const char*)p}; }
-VKRT_DEV float4 bufLoad4(BufView b, uint32_t byteOffset) { return *(const float4*)(b.p + byteOffset); }
-VKRT_DEV uint32_t bufLoad1(BufView b, uint32_t byteOffset) { return *(const uint32_t*)(b.p + byteOffset); }
-#else
 typedef unsigned vkrt_v4u __attribute__((ext_vector_type(4)));
 struct BufView { __amdgpu_buffer_rsrc_t r; };
 VKRT_DEV BufView bufView(const void* p) { return BufView{__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)0xffffffffu, 0x00020000)}; }
@@ -58,7 +51,6 @@ VKRT_DEV float4 bufLoad4(BufView b, uint32_t byteOffset)
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 VKRT_DEV uint32_t bufLoad1(BufView b, uint32_t byteOffset) { return __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)byteOffset, 0, 0); }
-#endif
 
 // i mod n in [0, n) for n > 0 (REPEAT addressing); power-of-two sizes take the mask path
 VKRT_DEV int wrapi(int i, int n)

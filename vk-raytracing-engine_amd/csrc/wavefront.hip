@@ -504,9 +504,6 @@ VKRT_DEV void shadeRound(const TraceParams& P, const WfBuffers& B, const HybridG
   else if((blk -= nP) < nS)
     shadeShadowBlock<HYBRID>(P, B, G, par, cS, blk, lds);
 }
-#ifdef VKRT_SHADE_WAVES
-__attribute__((amdgpu_waves_per_eu(VKRT_SHADE_WAVES)))
-#endif
 __global__ __launch_bounds__(WF_BLOCK) void k_wf_shade(const TraceParams P, const WfBuffers B, const int round)
 {
   const HybridGi none{};
