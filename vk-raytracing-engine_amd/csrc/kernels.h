@@ -47,6 +47,10 @@ struct WfOptions
 // frames >= 1: frame k uses pc.frame + k and seed + k * seedStep
 hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const WfOptions& opt, int frames, uint32_t seedStep, bool count,
                                  hipStream_t stream, WfTiming* timing, const WfAsync* async);
+// one launch of k_wf_traverse on the records of round r (wf_traverse.hip): travBlock 64 / 128 / 256 threads per workgroup, tg = grid,
+// tlds = LDS bytes of the per-lane stacks; count = the instrumented instantiation.  Launch errors surface through hipGetLastError.
+void       vkrt_wf_launch_traverse(const TraceParams& P, const WfBuffers& B, int r, unsigned travBlock, bool count, dim3 tg, size_t tlds,
+                                   hipStream_t stream);
 
 // hybrid mode (hybrid.hip)
 struct NrdPlanes  // optional NRD front-end attachments (include/vkrt.h vkrt_nrd_planes) + the raster pass's view matrix

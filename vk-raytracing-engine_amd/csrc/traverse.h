@@ -29,7 +29,8 @@ VKRT_DEV float safe_inv(float d)
 // trees; 1e-6 / 2e-6: 1 in 1e6; with the values below (incidence cosines down to ~0.05 covered) none in 2e6 pixels x 2 frames.
 #define VKRT_BOX_PAD_ABS 2.0e-5f   // slabs widened by this x max(|t0|, |t1|) per axis
 #define VKRT_BOX_PAD_REL 1.00004f  // far side (and the current best t) scaled by this
-#define VKRT_BOX_PAD_NEAR 0.99996f // wide8: near planes scaled by this (a near plane behind the origin is clamped by tmin anyway)
+#define VKRT_BOX_PAD_REL2 1.00008f // wide8: the far side carries the relative margin of both sides -- tn (1 - 4e-5) <= tf (1 + 4e-5) is
+                                   // tn <= tf (1 + 8e-5) for the tn > 0 that matter (tn >= tmin); near planes are left unscaled
 
 // conservative slab test against one child box; returns hit and entry distance
 VKRT_DEV bool box_test(f3 o, f3 id, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float tmax,

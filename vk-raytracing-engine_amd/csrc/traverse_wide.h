@@ -72,19 +72,19 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
   const float asz = __uint_as_float(((ew >> 16) & 0xffu) << 23) * id.z;
   const float aox = (q0.x - o.x) * id.x, aoy = (q0.y - o.y) * id.y, aoz = (q0.z - o.z) * id.z;
   // Conservative pads folded into per-node constants (margins: traverse.h): near planes move down and far planes up by an
-  // absolute pad, and both carry a relative pad through their scale and offset (far x (1 + 4e-5), near x (1 - 4e-5); a plane
-  // behind the origin only matters when the box is missed anyway).
+  // absolute pad; the relative pad of both sides sits on the far planes (scale and offset x (1 + 8e-5), and so the current best t):
+  // six multiplies per node test less than scaling the near side by (1 - 4e-5) as well (profiles/r04_experiments.md #126).
   // (the absolute pad scales with the largest |t| a plane of this node can have on the axis, |adj_origin| + QMAX |adj_scale|: a pad
   // relative to |adj_origin| alone vanishes when the node origin shares a coordinate with the ray origin -- a ray leaving a
   // wall along the wall, 1/d ~ 1e6 -- and then a hit 2e-8 outside the slab was pruned, r01_experiments.md #44)
   const float padx = VKRT_BOX_PAD_ABS * fmaf((float)VKRT_WNODE_QMAX, fabsf(asx), fabsf(aox));
   const float pady = VKRT_BOX_PAD_ABS * fmaf((float)VKRT_WNODE_QMAX, fabsf(asy), fabsf(aoy));
   const float padz = VKRT_BOX_PAD_ABS * fmaf((float)VKRT_WNODE_QMAX, fabsf(asz), fabsf(aoz));
-  const float nox = (aox - padx) * VKRT_BOX_PAD_NEAR, fox = (aox + padx) * VKRT_BOX_PAD_REL;
-  const float noy = (aoy - pady) * VKRT_BOX_PAD_NEAR, foy = (aoy + pady) * VKRT_BOX_PAD_REL;
-  const float noz = (aoz - padz) * VKRT_BOX_PAD_NEAR, foz = (aoz + padz) * VKRT_BOX_PAD_REL;
-  const float fsx = asx * VKRT_BOX_PAD_REL, fsy = asy * VKRT_BOX_PAD_REL, fsz = asz * VKRT_BOX_PAD_REL;
-  const float nsx = asx * VKRT_BOX_PAD_NEAR, nsy = asy * VKRT_BOX_PAD_NEAR, nsz = asz * VKRT_BOX_PAD_NEAR;  // near planes: t * (1 - 4e-5)
+  const float nox = aox - padx, fox = (aox + padx) * VKRT_BOX_PAD_REL2;
+  const float noy = aoy - pady, foy = (aoy + pady) * VKRT_BOX_PAD_REL2;
+  const float noz = aoz - padz, foz = (aoz + padz) * VKRT_BOX_PAD_REL2;
+  const float fsx = asx * VKRT_BOX_PAD_REL2, fsy = asy * VKRT_BOX_PAD_REL2, fsz = asz * VKRT_BOX_PAD_REL2;
+  const float nsx = asx, nsy = asy, nsz = asz;
   // quantised planes, near/far by ray direction sign
   const unsigned lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
   const unsigned lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
@@ -113,7 +113,7 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
       const float tny = fmaf(VKRT_WN_PLANE(ny, w, k), nsy, noy), tfy = fmaf(VKRT_WN_PLANE(fy, w, k), fsy, foy);
       const float tnz = fmaf(VKRT_WN_PLANE(nz, w, k), nsz, noz), tfz = fmaf(VKRT_WN_PLANE(fz, w, k), fsz, foz);
       const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * VKRT_BOX_PAD_REL));
+      const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * VKRT_BOX_PAD_REL2));
       const unsigned piece = ((bits4 >> (8 * k)) & 0xffu) << ((bitIndex4 >> (8 * k)) & 0xffu);
       hitmask |= (tn <= tf) ? piece : 0u;
     }

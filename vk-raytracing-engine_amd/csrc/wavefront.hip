@@ -47,56 +47,7 @@
 #define WF_BLOCK 256
 #define VKRT_FLAG_COUNT_WORK 2u  // = VKRT_TRACE_COUNT_TRAVERSAL (include/vkrt.h)
 
-// ---- streams ---------------------------------------------------------------------------------------------------------
-// Six streams [parity][type] of float4 planes with room for `capacity` records (storage: plane() below).  type 0 "C": the path's next ray is a closest-hit
-// ray; type 1 "S": a shadow ray, and the segment it belongs to is the last of its sample; type 2 "P" (pair): the shadow ray
-// of segment k and the closest-hit ray of segment k + 1, both from the hit point of segment k.
-//   plane 0  R0  ray origin.xyz, tmax of the first ray (C: 10000; S, P: lightDist - 0.1)      written by the producer
-//   plane 1  R1  direction of the first ray (C: closest-hit ray; S, P: shadow ray), S, P: lightDist (read by the hybrid mode only)
-//   plane 2  R2  P: direction of the closest-hit ray of the next segment (prd.rayDirection), -
-//   plane 3  H0  written by k_wf_traverse.  C: t, u, v, instance id (-1 = miss).  S: .w = 0 occluded / -1 not.
-//                P: .x = 1 occluded / 0 not (stored by the shadow lane), .y .z .w = u, v, instance id of the closest-hit ray
-//   plane 4  H1  C, P: triShade record of the closest hit
-//   plane 5  S0  path weight.xyz (C: curWeight; S, P: weight after the segment the shadow ray belongs to), seed
-//   plane 6  S1  hitValue.xyz (radiance of the current sample), flags
-//   plane 7  S2  hitValues.xyz (sum over finished samples), px | lrow << 16
-//   plane 8  S3  S, P: clamped contribution of the segment if its light is visible (rgen:99-102), -
-// flags: depth[0:8) | smpl[8:24) | isSpecular[25]
-#define WF_PLANES 9
-#define WF_TYPES 3
-enum { WF_R0 = 0, WF_R1, WF_R2, WF_H0, WF_H1, WF_S0, WF_S1, WF_S2, WF_S3 };
-enum { WF_C = 0, WF_S = 1, WF_P = 2 };
-
-// Storage.  A path is in exactly one stream, so the C and the S records of a round together never outnumber the paths: the two streams
-// share their planes -- C records fill a plane from the front, S records from the back (record i of S lives at capacity - 1 - i; a
-// wave still reads 1 KB contiguous) -- and neither of them has an R2 field.  17 planes per parity instead of 27: 544 B per path.
-#define WF_SLOTS_CS 8  // R0 R1 H0 H1 S0 S1 S2 S3 (C leaves S3 unused, S leaves H1 unused)
-#define WF_SLOTS (WF_SLOTS_CS + WF_PLANES)  // + the nine planes of the pair stream
-VKRT_DEV float4* plane(const WfBuffers& B, int parity, int type, int k)
-{
-  const int slot = type == WF_P ? WF_SLOTS_CS + k : (k > WF_R2 ? k - 1 : k);
-  return B.planes + ((size_t)(parity * WF_SLOTS + slot)) * B.capacity;
-}
-VKRT_DEV unsigned* countOf(const WfBuffers& B, int parity, int type) { return &B.ctrl[parity * 4 + type]; }
-// record i of a plane: the plane's base is uniform (kernel arguments, round parity, the workgroup's stream type) and the record's byte
-// offset fits 32 bits (capacity < 2^28 paths, checked at launch), so the access is "scalar base + 32-bit lane offset": one address
-// VGPR per access instead of two (the shade kernel holds a dozen of them at once)
-VKRT_DEV float4* rec(const WfBuffers& B, int parity, int type, int k, unsigned i)
-{
-  return (float4*)((char*)plane(B, parity, type, k) + (size_t)((type == WF_S ? B.capacity - 1u - i : i) * 16u));
-}
-
-// Stream records are written by one kernel and consumed by the next one or two (the traversal kernel reads the ray planes, the shade
-// kernel the rest; the direction and seed planes are read by both): no later round reads them again, so they are fetched with non-temporal
-// loads (the `nt` policy bit) and do not displace tree nodes and triangles from L2 / Infinity Cache on their way out: +1.5 % ray rate on
-// the bench scene, +1.8 % on the Sponza-like one.  The stores stay ordinary -- the next kernel reads the records from the caches; written
-// non-temporally they come back from HBM and the frame is 4.5 % slower (profiles/r03_experiments.md #103).
-VKRT_DEV float4 wfLoad(const float4* p)
-{
-  const vkrt_v4f v = __builtin_nontemporal_load((const vkrt_v4f*)p);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-VKRT_DEV void wfStore(float4* p, float4 v) { *p = v; }
+#include "wf_streams.h"
 
 VKRT_DEV unsigned packFlags(const LaneState& L)
 {
@@ -220,109 +171,6 @@ __global__ __launch_bounds__(WF_BLOCK) void k_wf_init(const TraceParams P, const
   __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (WF_BLOCK / 64)];
   const unsigned vals[6] = {0, 0, 0, 0, 0, nPixels};
   blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 6, red);
-}
-
-// Ray kinds a traversal workgroup can hold, in dispatch order: heavy closest-hit walks first, any-hit walks behind them.
-enum { WF_K_CLOSEST_C = 0, WF_K_CLOSEST_P = 1, WF_K_SHADOW_S = 2, WF_K_SHADOW_P = 3 };
-
-// result of a finished walk -> its record
-VKRT_DEV void storeHit(const TraceParams& P, const WfBuffers& B, int par, int kind, unsigned qi, const RayHit& hit)
-{
-  if(kind == WF_K_SHADOW_S)
-    wfStore(rec(B, par, WF_S, WF_H0, qi), make_float4(0.0f, 0.0f, 0.0f, __int_as_float(hit.slot >= 0 ? 0 : -1)));
-  else if(kind == WF_K_SHADOW_P)
-    ((float*)rec(B, par, WF_P, WF_H0, qi))[0] = __int_as_float(hit.slot >= 0 ? 1 : 0);  // the closest-hit lane of the record owns .yzw
-  else
-  {
-    const int type = kind == WF_K_CLOSEST_C ? WF_C : WF_P;
-    int inst = -1;
-    if(hit.slot >= 0)
-    {
-      // first hops of the hit shader's attribute fetch, taken here: the triangle's shading record and its instance id
-      // travel with the hit, so the closest-hit shading starts at the vertex / material loads
-      const uint4 ts = P.sc.triShade[hit.slot];
-      inst = __float_as_int(P.sc.tris[hit.slot * VKRT_TRI_QUADS + 2].z);
-      wfStore(rec(B, par, type, WF_H1, qi), make_float4(__uint_as_float(ts.x), __uint_as_float(ts.y), __uint_as_float(ts.z), __uint_as_float(ts.w)));
-    }
-    float* h = (float*)rec(B, par, type, WF_H0, qi);
-    if(type == WF_C)
-      wfStore(rec(B, par, WF_C, WF_H0, qi), make_float4(hit.t, hit.u, hit.v, __int_as_float(inst)));
-    else
-    {
-      h[1] = hit.u; h[2] = hit.v; h[3] = __int_as_float(inst);
-    }
-  }
-}
-
-// ---- traversal: one thread per queued ray, workgroups homogeneous in ray kind -----------------------------------
-template <bool COUNT, bool WIDE, int TB, int TM = 0>
-__global__ __launch_bounds__(TB)
-__attribute__((amdgpu_waves_per_eu(TM != 0 && WIDE && TB == 64 ? 5 : 1)))
-void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
-{
-  extern __shared__ int lds_stack[];
-  const int par = round & 1;
-  const unsigned cC = *countOf(B, par, WF_C), cS = *countOf(B, par, WF_S), cP = *countOf(B, par, WF_P);
-  if(blockIdx.x == 0 && threadIdx.x == 0)
-  {
-    for(int t = 0; t < WF_TYPES; t++) *countOf(B, par ^ 1, t) = 0u;  // next round's counts; this round's shade kernel claims slots from them
-    // every slot below the counts is traced exactly once: the ray counters of the launch are the stream counts
-    if(cC + cP) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][0], (unsigned long long)cC + cP);
-    if(cS + cP) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][1], (unsigned long long)cS + cP);
-  }
-  // block ranges: [closest rays of C][closest rays of P][shadow rays of S][shadow rays of P]
-  const unsigned nC = (cC + TB - 1) / TB, nP = (cP + TB - 1) / TB, nS = (cS + TB - 1) / TB;
-  unsigned blk = blockIdx.x;
-  int kind;
-  unsigned count;
-  if(blk < nC) { kind = WF_K_CLOSEST_C; count = cC; }
-  else if((blk -= nC) < nP) { kind = WF_K_CLOSEST_P; count = cP; }
-  else if((blk -= nP) < nS) { kind = WF_K_SHADOW_S; count = cS; }
-  else if((blk -= nS) < nP) { kind = WF_K_SHADOW_P; count = cP; }
-  else return;
-  const bool anyHit = kind >= WF_K_SHADOW_S;  // workgroup-uniform
-  const int type = kind == WF_K_CLOSEST_C ? WF_C : kind == WF_K_SHADOW_S ? WF_S : WF_P;
-  const unsigned qi = blk * TB + threadIdx.x;
-  const bool valid = qi < count;
-  // the ray of this lane: origin from R0; the shadow ray of a pair record and every C / S ray take R1 and R0.w, the closest-hit
-  // ray of a pair record takes R2 and the closest-hit tmax
-  float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-  if(valid)
-  {
-    r0 = wfLoad(rec(B, par, type, WF_R0, qi));
-    r1 = wfLoad(rec(B, par, type, kind == WF_K_CLOSEST_P ? WF_R2 : WF_R1, qi));
-    if(kind == WF_K_CLOSEST_P)
-      r0.w = 10000.0f;
-  }
-  // any-hit stage: the payload's seed when the ray is traced (S0.w: after the shading that produced the ray, raytrace.rgen:64-97)
-  uint32_t raySeed = 0u;
-  if((TM & VKRT_TM_DISSOLVE) && valid)
-    raySeed = __float_as_uint(wfLoad(rec(B, par, type, WF_S0, qi)).w);
-  TravCount tc;
-  __shared__ int shareLds[VKRT_SHARE_LDS_WORDS];
-  RayHit hit;
-  if(WIDE && TB == 64 && P.sc.shareMinIdle != 0u && P.sc.triThreshold != 0u)  // launch-uniform
-  {
-    // the whole wave walks together: lanes past the end of the stream have no ray of their own but help
-    uint2* stk = ((uint2*)lds_stack) + threadIdx.x;
-    if(anyHit)
-      traverse_wide8_share<COUNT, true, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
-    else
-      traverse_wide8_share<COUNT, false, TM>(P.sc, valid, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, stk, shareRes(shareLds), hit, tc, raySeed);
-    if(valid)
-      storeHit(P, B, par, kind, qi, hit);
-  }
-  else if(valid)
-  {
-    traverse_any<COUNT, WIDE, TM>(P.sc, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), 0.001f, r0.w, anyHit, lds_stack, (int)threadIdx.x, TB, hit, tc, raySeed);
-    storeHit(P, B, par, kind, qi, hit);
-  }
-  if(COUNT)
-  {
-    __shared__ unsigned long long red[VKRT_COUNTER_STRIDE * (TB / 64)];
-    const unsigned vals[10] = {0, 0, 0, 0, 0, 0, tc.nodes, tc.tris, tc.waveNodeSteps, tc.waveTriSteps};
-    blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 10, red);
-  }
 }
 
 // ---- hybrid mode: the GI path of raytraceHybrid.rgen:172-282 on the same streams ----------------------------------------------
@@ -625,38 +473,6 @@ void vkrt_wf_carve(void* base, uint32_t pathCapacity, int groups, WfBuffers* B)
   B->groups = (uint32_t)g;
 }
 
-// One traversal launch: the instantiation for (instrumented?, node layout, workgroup size, triangle mode).  The non-default triangle
-// modes (watertight test, any-hit dissolve stage) are built for the default 64-thread workgroups only (vkrt_accel_build refuses the
-// other sizes with them).
-static void launchTraverse(const TraceParams& P, const WfBuffers& B, int r, unsigned travBlock, bool count, dim3 tg, size_t tlds, hipStream_t stream)
-{
-  const bool wide = P.sc.layout == 1u;
-  const int tm = (P.sc.watertight ? VKRT_TM_WATERTIGHT : 0) | (P.sc.dissolve ? VKRT_TM_DISSOLVE : 0);
-  const dim3 tb(travBlock);
-#define VKRT_TRAV_LAUNCH(C, W, TB, TM) hipLaunchKernelGGL((k_wf_traverse<C, W, TB, TM>), tg, tb, tlds, stream, P, B, r)
-#define VKRT_TRAV_MODES(TB, TM)                                                                                                        \
-  do {                                                                                                                                 \
-    if(wide) { if(count) VKRT_TRAV_LAUNCH(true, true, TB, TM); else VKRT_TRAV_LAUNCH(false, true, TB, TM); }                           \
-    else { if(count) VKRT_TRAV_LAUNCH(true, false, TB, TM); else VKRT_TRAV_LAUNCH(false, false, TB, TM); }                             \
-  } while(0)
-  if(travBlock == 64)
-  {
-    switch(tm)
-    {
-      case 0: VKRT_TRAV_MODES(64, 0); break;
-      case 1: VKRT_TRAV_MODES(64, 1); break;
-      case 2: VKRT_TRAV_MODES(64, 2); break;
-      default: VKRT_TRAV_MODES(64, 3); break;
-    }
-  }
-  else if(travBlock == 128)
-    VKRT_TRAV_MODES(128, 0);
-  else
-    VKRT_TRAV_MODES(256, 0);
-#undef VKRT_TRAV_MODES
-#undef VKRT_TRAV_LAUNCH
-}
-
 // One sub-frame = the tiles [tileFirst, tileFirst + tileCount) of the shard with their own streams and counts, on one HIP stream.
 // subframeBegin: counts cleared, one closest-ray record per pixel (raytrace.rgen:27-60).
 static hipError_t subframeBegin(const TraceParams& P, const WfBuffers& B, hipStream_t stream)
@@ -682,7 +498,7 @@ static void subframeRound(const TraceParams& P, const WfBuffers& B, int r, unsig
   const bool timed = timing && timing->events && 2 * (timing->used + 1) <= timing->capacity;
   if(timed)
     (void)hipEventRecord(timing->events[2 * timing->used], stream);
-  launchTraverse(P, B, r, travBlock, count, tg, tlds, stream);
+  vkrt_wf_launch_traverse(P, B, r, travBlock, count, tg, tlds, stream);
   if(timed)
   {
     (void)hipEventRecord(timing->events[2 * timing->used + 1], stream);
@@ -879,7 +695,7 @@ hipError_t vkrt_launch_hybrid_gi(const TraceParams& P, const WfBuffers& B, const
   const size_t tlds = (size_t)P.sc.stackCap * tbs * sizeof(int);
   for(int r = 0; r < rounds; r++)
   {
-    launchTraverse(P, B, r, tbs, false, tg, tlds, stream);
+    vkrt_wf_launch_traverse(P, B, r, tbs, false, tg, tlds, stream);
     hipLaunchKernelGGL(k_wf_shade_hybrid, dim3(blocks + 3), dim3(WF_BLOCK), 0, stream, P, B, G, r);
   }
   return hipGetLastError();
