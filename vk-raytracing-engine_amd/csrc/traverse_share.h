@@ -171,15 +171,13 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
       }
     }
     // ---- one step of every busy lane's walk (same step as w8run) -----------------------------------------------------
-    bool found = false;  // this lane has a candidate hit to publish
-    float ct = 0.0f, cu = 0.0f, cv = 0.0f;
-    int cslot = -1, cgid = 0;
     shareSync();  // results published in the previous step are visible to every lane of the ray
     if(busy)
     {
       float bt = tmax;
       int bg = -1;
       bool finished = false;
+      bool occluded = false;  // any-hit walks: this lane found an occluder in this step
       if(ANYHIT)
         finished = __hip_atomic_load(&res.slot[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >= 0;  // somebody already found an occluder for this ray
       else
@@ -190,7 +188,15 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
       }
       if(!finished)
       {
-        auto testOne = [&]() {
+        // A candidate hit lives only between the tests of one site and its publication right behind them (kept across the whole
+        // step, its six registers were re-initialised on every level of the nested control flow: 20 v_mov_b32 per iteration).
+        struct Cand
+        {
+          bool found;
+          float t, u, v;
+          int slot, gid;
+        };
+        auto testOne = [&](Cand& cd) {
           const unsigned i = (unsigned)__ffs((int)T.y) - 1u;
           T.y &= T.y - 1u;
           const unsigned s = T.x + i;
@@ -208,22 +214,53 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           {
             if(ANYHIT)
             {
-              if(t < tmax && !found && !anyhit_ignores<TM>(sc, s, c.y, raySeed))
+              if(t < tmax && !cd.found && !anyhit_ignores<TM>(sc, s, c.y, raySeed))
               {
-                found = true; ct = t; cslot = (int)s;
+                cd.found = true; cd.t = t; cd.slot = (int)s;
               }
             }
             else
             {
               const int gid = tri_gid<TM>(c.y);
-              const float rt = found ? ct : bt;
-              const int rg = found ? cgid : bg;
+              const float rt = cd.found ? cd.t : bt;
+              const int rg = cd.found ? cd.gid : bg;
               if((t < rt || (t == rt && gid < rg)) && !anyhit_ignores<TM>(sc, s, c.y, raySeed))
               {
-                found = true; ct = t; cu = u; cv = v; cslot = (int)s; cgid = gid;
+                cd.found = true; cd.t = t; cd.u = u; cd.v = v; cd.slot = (int)s; cd.gid = gid;
               }
             }
           }
+        };
+        // publish an improvement: LDS atomic minimum on (t, id), the winner leaves its payload.  Called where the candidate was found,
+        // by the lanes that found one: the lanes of a site run it in lockstep, and the sequences of two sites never interleave.
+        auto publish = [&](const Cand& cd) {
+          if(!cd.found)
+            return;
+          if(ANYHIT)
+          {
+            __hip_atomic_store(&res.slot[owner], cd.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            occluded = true;
+          }
+          else
+          {
+            // (t bits, triangle id) is unique per candidate, so "the minimum is mine" identifies exactly one winner among the
+            // lanes publishing for this ray in this step; it alone writes the payload.  Keys only decrease.
+            const unsigned long long mine = ((unsigned long long)__float_as_uint(cd.t) << 32) | (unsigned)cd.gid;
+            __hip_atomic_fetch_min(&res.key[owner], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            shareSync();  // every lane's minimum has been applied before anyone checks who won
+            if(__hip_atomic_load(&res.key[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == mine)
+            {
+              res.slot[owner] = cd.slot; res.u[owner] = cd.u; res.v[owner] = cd.v;
+            }
+            bt = cd.t; bg = cd.gid;  // (the ray's best is at least this good now)
+          }
+        };
+        // test a whole group out on the spot (rare: a parked group in the way of a node push, or no room to park)
+        auto flushT = [&]() {
+          Cand cd = {false, 0.0f, 0.0f, 0.0f, -1, 0};
+          while(T.y != 0u && !(ANYHIT && cd.found))
+            testOne(cd);
+          publish(cd);
         };
         if(G.y & 0xff000000u)
         {
@@ -240,8 +277,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
               const uint2 keep = T;
               T = stk[(cap - nPost) * stride];
               nPost--;
-              while(T.y != 0u && !(ANYHIT && found))
-                testOne();
+              flushT();
               T = keep;
             }
             if(sp + nPost < cap)
@@ -265,8 +301,8 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
               }
               else
               {
-                while(T.y != 0u && !(ANYHIT && found))
-                  testOne();
+                if(!occluded)
+                  flushT();
                 T.y = 0u;
               }
             }
@@ -291,11 +327,15 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
         if(sc.triThreshold > 1u)
           triStep = (unsigned)__popcll(__ballot(T.y != 0u)) * 64u >= sc.triThreshold * (unsigned)__popcll(busyMask) ||
                     __ballot((G.y & 0xff000000u) != 0u) == 0ull;
-        if(T.y != 0u && triStep && !(ANYHIT && found))
-          testOne();
+        if(T.y != 0u && triStep && !occluded)
+        {
+          Cand cd = {false, 0.0f, 0.0f, 0.0f, -1, 0};
+          testOne(cd);
+          publish(cd);
+        }
         // (testing two or three triangles per lane in steps where no lane of the wave has node work left -- all loop overhead around one
         //  test -- did not pay: 4110 -> 4082 / 4078 Mrays/s on the strip scene, profiles/r04_experiments.md #116c)
-        if(ANYHIT && found)
+        if(ANYHIT && occluded)
           finished = true;
         else if((G.y & 0xff000000u) == 0u && T.y == 0u && nPost == 0)
           finished = true;  // (sp == sb here: the refill above would have popped otherwise)
@@ -307,24 +347,6 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
       }
       if(finished)
         busy = false;  // (G, T and the stack indices are dead until the lane adopts new work)
-    }
-    // ---- publish improvements: LDS atomic minimum on (t, id), the winner leaves its payload ------------------------------
-    if(found)
-    {
-      if(ANYHIT)
-        __hip_atomic_store(&res.slot[owner], cslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      else
-      {
-        // (t bits, triangle id) is unique per candidate, so "the minimum is mine" identifies exactly one winner among the
-        // lanes publishing for this ray in this step; it alone writes the payload.  Keys only decrease.
-        const unsigned long long mine = ((unsigned long long)__float_as_uint(ct) << 32) | (unsigned)cgid;
-        __hip_atomic_fetch_min(&res.key[owner], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        shareSync();  // every lane's minimum has been applied before anyone checks who won
-        if(__hip_atomic_load(&res.key[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == mine)
-        {
-          res.slot[owner] = cslot; res.u[owner] = cu; res.v[owner] = cv;
-        }
-      }
     }
   }
   shareSync();
