@@ -52,6 +52,22 @@ VKRT_DEV void w8_begin(const DevScene& sc, W8State<TM>& S, f3 o, f3 d, float tma
   S.anyHit = anyHit;
 }
 
+// byte k of bits4 shifted left by byte k of idx4 (its bits [4:0]): ONE instruction with SDWA byte selects on both operands, where the
+// compiler emits v_bfe_u32 + v_lshrrev_b32 + v_lshlrev_b32 -- eight times per node test (profiles/r04_experiments.md #127)
+VKRT_DEV unsigned w8_piece(unsigned idx4, unsigned bits4, int k)
+{
+  unsigned r;
+  if(k == 0)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(idx4), "v"(bits4));
+  else if(k == 1)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(idx4), "v"(bits4));
+  else if(k == 2)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(r) : "v"(idx4), "v"(bits4));
+  else
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(idx4), "v"(bits4));
+  return r;
+}
+
 // Test the 8 children of wide node `child` against the ray: G = (child base, hit internal children | imask),
 // T = (triangle base, 24-bit mask of the leaf triangles whose boxes the ray touched).
 template <bool COUNT>
@@ -104,7 +120,7 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
     const unsigned meta4 = __float_as_uint(w == 0 ? q1.z : q1.w);
     const unsigned inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;         // bit 4 of a byte set <=> internal (24..31)
     const unsigned innerMask4 = (inner4 >> 4) * 0x07u;                      // 0x07 per internal byte
-    const unsigned bitIndex4 = (meta4 ^ (octinv * 0x01010101u & innerMask4)) & 0x1f1f1f1fu;
+    const unsigned bitIndex4 = meta4 ^ (octinv * 0x01010101u & innerMask4);  // (a shift reads bits [4:0] of its count: no mask)
     const unsigned bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
     for(int k = 0; k < 4; k++)
@@ -114,7 +130,7 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
       const float tnz = fmaf(VKRT_WN_PLANE(nz, w, k), nsz, noz), tfz = fmaf(VKRT_WN_PLANE(fz, w, k), fsz, foz);
       const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
       const float tf = fminf(fminf(tfx, tfy), fminf(tfz, bestT * VKRT_BOX_PAD_REL2));
-      const unsigned piece = ((bits4 >> (8 * k)) & 0xffu) << ((bitIndex4 >> (8 * k)) & 0xffu);
+      const unsigned piece = w8_piece(bitIndex4, bits4, k);
       hitmask |= (tn <= tf) ? piece : 0u;
     }
   }
