@@ -65,7 +65,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
   int owner = lane;  // home lane of the ray this lane is working on
   f3 id = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   bool px = !(id.x < 0.0f), py = !(id.y < 0.0f), pz = !(id.z < 0.0f);
-  unsigned octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+  unsigned oct4 = ((px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u)) * 0x01010101u;  // octinv in every byte (w8_test_children)
   uint2 G = make_uint2(0u, (valid && sc.rootRef != VKRT_TRAV_DONE) ? 0x80000000u : 0u);
   uint2 T = make_uint2(0u, 0u);
   int sp = 0, sb = 0, nPost = 0;  // node groups live in [sb, sp), parked triangle groups in [cap - nPost, cap)
@@ -152,7 +152,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
           tr.set(d);  // (watertight: the adopted ray's shear constants, recomputed rather than shuffled)
           farFirst = ANYHIT && anyhit_far_first(sc, o, d, tmax);
           px = !(id.x < 0.0f); py = !(id.y < 0.0f); pz = !(id.z < 0.0f);
-          octinv = (px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u);
+          oct4 = ((px ? 1u : 0u) | (py ? 2u : 0u) | (pz ? 4u : 0u)) * 0x01010101u;
           if(ex & 0x80000000u)  // a triangle group of the donor's ray: nothing to walk, only to test
           {
             G = make_uint2(0u, 0u);
@@ -266,7 +266,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
         {
           // closest-hit walks go front to back; any-hit walks take the FARTHEST pending child first (farFirst): see anyhit_far_first
           const unsigned bitIdx = farFirst ? (unsigned)__ffs((int)(G.y & 0xff000000u)) - 1u : 31u - (unsigned)__clz((int)G.y);
-          const unsigned slot = (bitIdx - 24u) ^ octinv;
+          const unsigned slot = (bitIdx - 24u) ^ (oct4 & 7u);
           const unsigned child = G.x + (unsigned)__popc(G.y & 0xffu & ((1u << slot) - 1u));
           G.y &= ~(1u << bitIdx);
           if(G.y & 0xff000000u)
@@ -289,7 +289,7 @@ VKRT_DEV void traverse_wide8_share(const DevScene& sc, bool valid, f3 o, f3 d, f
               VKRT_TRAV_FAULT(sc);
           }
           uint2 Tn;
-          w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bt, G, Tn, tc);
+          w8_test_children<COUNT>(nodes, child, o, id, oct4, px, py, pz, tmin, bt, G, Tn, tc);
           if(Tn.y != 0u)
           {
             if(T.y != 0u)

@@ -68,10 +68,11 @@ VKRT_DEV unsigned w8_piece(unsigned idx4, unsigned bits4, int k)
   return r;
 }
 
-// Test the 8 children of wide node `child` against the ray: G = (child base, hit internal children | imask),
+// Test the 8 children of wide node `child` against the ray (oct4 = the ray's octinv in each of the four bytes, a per-ray constant the
+// callers keep: one v_mul_lo_u32 per node test otherwise): G = (child base, hit internal children | imask),
 // T = (triangle base, 24-bit mask of the leaf triangles whose boxes the ray touched).
 template <bool COUNT>
-VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child, f3 o, f3 id, unsigned octinv, bool px, bool py, bool pz, float tmin,
+VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child, f3 o, f3 id, unsigned oct4, bool px, bool py, bool pz, float tmin,
                                float bestT_in, uint2& G, uint2& T, TravCount& tc)
 {
   const float4* __restrict__ np = nodes + (size_t)child * VKRT_WNODE_QUADS;  // one 64-bit address, immediate offsets
@@ -120,7 +121,7 @@ VKRT_DEV void w8_test_children(const float4* __restrict__ nodes, unsigned child,
     const unsigned meta4 = __float_as_uint(w == 0 ? q1.z : q1.w);
     const unsigned inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;         // bit 4 of a byte set <=> internal (24..31)
     const unsigned innerMask4 = (inner4 >> 4) * 0x07u;                      // 0x07 per internal byte
-    const unsigned bitIndex4 = meta4 ^ (octinv * 0x01010101u & innerMask4);  // (a shift reads bits [4:0] of its count: no mask)
+    const unsigned bitIndex4 = meta4 ^ (oct4 & innerMask4);  // (a shift reads bits [4:0] of its count: no mask)
     const unsigned bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
     for(int k = 0; k < 4; k++)
@@ -173,7 +174,7 @@ VKRT_DEV bool w8_iterate(const DevScene& sc, W8State<TM>& S, float tmin, uint2* 
       VKRT_TRAV_FAULT(sc);
       return false;
     }
-    w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, S.bestT, G, T, tc);
+    w8_test_children<COUNT>(nodes, child, o, id, octinv * 0x01010101u, px, py, pz, tmin, S.bestT, G, T, tc);
   }
   // triangles of this node that the ray's boxes touched
   while(T.y != 0u)
@@ -336,7 +337,7 @@ VKRT_DEV void traverse_wide8_postpone(const DevScene& sc, f3 o, f3 d, float tmin
           VKRT_TRAV_FAULT(sc);
       }
       uint2 Tn;
-      w8_test_children<COUNT>(nodes, child, o, id, octinv, px, py, pz, tmin, bestT, G, Tn, tc);
+      w8_test_children<COUNT>(nodes, child, o, id, octinv * 0x01010101u, px, py, pz, tmin, bestT, G, Tn, tc);
       if(Tn.y != 0u)
       {
         if(T.y != 0u)
