@@ -62,7 +62,7 @@ def test_traversal_kernel_has_no_packed_fp32_and_keeps_five_waves(traverse_asm):
 
 def test_node_test_uses_one_sdwa_shift_per_child(traverse_asm):
     body, _ = traverse_asm
-    # six copies of the node test in the kernel (two sharing loops, two plain loops, two flush paths), eight children each (#128)
+    # six copies of the node test in the kernel (two sharing loops, two plain loops, two flush paths), eight children each (#127)
     sdwa = re.findall(r"v_lshlrev_b32_sdwa v\d+, v\d+, v\d+ dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_(\d) src1_sel:BYTE_(\d)", body)
     assert len(sdwa) >= 48 and len(sdwa) % 8 == 0, len(sdwa)
     assert all(a == b for a, b in sdwa)
@@ -72,6 +72,6 @@ def test_node_test_uses_one_sdwa_shift_per_child(traverse_asm):
 
 def test_candidate_registers_are_not_reinitialised_per_nesting_level(traverse_asm):
     body, _ = traverse_asm
-    # #127: the kernel had 460 v_mov_b32 with the candidate hit live across a whole step (358 without the SLP moves); local candidates: ~340
+    # #128: the kernel had 460 v_mov_b32 with the candidate hit live across a whole step (358 without the SLP moves); local candidates: ~340
     movs = len(re.findall(r"^\s+v_mov_b32", body, flags=re.M))
     assert movs < 400, movs
