@@ -150,6 +150,28 @@ def fresh_profile(path, key):
     return d
 
 
+def issue_mix_block(mix, valu_per_ray, node_wave_steps_per_ray, frac_of_peak):
+    """roofline.issue_mix: what the kernel's opcode mix allows.  A half-rate opcode (v_cvt_f32_ubyte*, v_min/max(3)_f32, v_cmp, SDWA and
+    VOP3 integer work; profiles/r02_issue_microbench.json) takes the issue slots of two full-rate ones, so a wave whose instructions
+    are a share h half-rate can reach at most 1 / (1 + h) of the full-rate peak.  h is estimated from the STATIC mix of the assembly
+    (profiles/isa_mix.json, tools/isa_blocks.py --json: the node-test block and the rest of the sharing loop) weighted by this run's
+    DYNAMIC counts: node wave-steps per wave (the kernel's own counters) x the node test's instructions; every other VALU instruction
+    the counters saw (profiles/pmc_issue.json) gets the static mix of the rest of the loop."""
+    per_wave = 64.0 * valu_per_ray
+    node_steps = 64.0 * node_wave_steps_per_ray
+    node_instr = min(node_steps * mix["node_test"]["valu"], per_wave)
+    rest_instr = per_wave - node_instr
+    rest_share = mix["loop_rest"]["half_rate"] / max(mix["loop_rest"]["valu"], 1)
+    half = node_instr * mix["node_test"]["half_rate"] / max(mix["node_test"]["valu"], 1) + rest_instr * rest_share
+    h = half / per_wave
+    ceiling = 1.0 / (1.0 + h)
+    return {"half_rate_share": h, "ceiling_frac_of_peak": ceiling, "frac_of_mix_ceiling": frac_of_peak / ceiling,
+            "valu_instr_per_wave": per_wave, "node_test_instr_per_wave": node_instr, "node_wave_steps_per_wave": node_steps,
+            "node_test": mix["node_test"], "loop_rest": mix["loop_rest"],
+            "note": "an estimate beside roofline.frac, not a replacement: static opcode classes of the assembly (profiles/isa_mix.json) weighted by "
+                    "the dynamic step counts of this run; frac_of_mix_ceiling = frac / ceiling_frac_of_peak"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -453,6 +475,12 @@ def main():
                         "peak_source": "MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per full-rate wave64 VALU instruction (= 157.3 TFLOP/s / 128 flop); "
                                        "peak_calibrated: profiles/r02_issue_microbench.json, best full-rate opcode class at 8 waves/SIMD; v_cvt_f32_ubyte*, "
                                        f"v_min/max(3)_f32, v_cmp, VOP3 integer ops issue at half the full rate ({half:.0f} G/s measured)"}
+                try:  # the ceiling the opcode mix allows (an estimate, kept apart from frac)
+                    im = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+                    if im.get("source_hash") == vkrt_amd.source_hash() and not stale and work["wave_node_steps"]:
+                        roof["issue_mix"] = issue_mix_block(im, pi["valu_wave_instr_per_ray"], work["wave_node_steps"] / rays_frame, roof["frac"])
+                except Exception:
+                    pass
             except Exception:
                 roof = None
             if roof is None:  # no issue profile at all: fall back to the byte view, labelled as what it is

@@ -137,3 +137,21 @@ def test_committed_bench_line_follows_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_issue_mix_estimate_is_the_ceiling_a_share_of_half_rate_opcodes_allows():
+    import bench
+
+    """roofline.issue_mix (bench.issue_mix_block): h = share of half-rate instructions, ceiling = 1 / (1 + h) of the full-rate peak."""
+    mix = {"node_test": {"valu": 200, "half_rate": 100}, "loop_rest": {"valu": 100, "half_rate": 0}}
+    b = bench.issue_mix_block(mix, valu_per_ray=100.0, node_wave_steps_per_ray=16.0 / 64.0, frac_of_peak=0.5)
+    assert b["valu_instr_per_wave"] == 6400.0 and b["node_test_instr_per_wave"] == 3200.0
+    assert abs(b["half_rate_share"] - 0.25) < 1e-12 and abs(b["ceiling_frac_of_peak"] - 0.8) < 1e-12
+    assert abs(b["frac_of_mix_ceiling"] - 0.625) < 1e-12
+    # the committed static mix (tools/isa_blocks.py --json) has the shape the estimate reads; bench.py ignores it when its source hash is stale
+    m = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+    assert m["node_test"]["valu"] >= m["node_test"]["half_rate"] > 0 and m["loop_rest"]["valu"] > 0 and "source_hash" in m
+    r = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))["roofline"]
+    steps = r["per_ray"]["nodes_visited"] / (64.0 * r["per_ray"]["node_step_lane_efficiency"])
+    e = bench.issue_mix_block(m, r["valu_wave_instr_per_ray"], steps, r["frac"])
+    assert 0.6 < e["ceiling_frac_of_peak"] < 0.8 and r["frac"] < e["frac_of_mix_ceiling"] < 1.0

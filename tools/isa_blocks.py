@@ -4,6 +4,9 @@ LDS / global-memory instruction counts and branch targets, and per loop the tota
 
     tools/isa_stats.sh            # writes /tmp/vkrt_isa/wf_traverse.s
     python tools/isa_blocks.py [/tmp/vkrt_isa/wf_traverse.s] [--blocks]
+    python tools/isa_blocks.py --json      # writes profiles/isa_mix.json: the static opcode mix of the sharing closest-hit loop (node
+                                           # test block / rest of the loop), tied to the sources by vkrt_amd.source_hash: bench.py's
+                                           # roofline.issue_mix prices the kernel against the ceiling that mix allows
 """
 import re
 import sys
@@ -67,6 +70,21 @@ def main():
         print(f"loop {h['name']}: {len(members)} blocks, VALU {tot['valu']} (half-rate {tot['half']}, v_mov {tot['mov']}), SALU {tot['salu']}, "
               f"LDS {tot['lds']} (bpermute {tot['bperm']}), memory {tot['vmem']}; node test {node['name']}: {node['valu']} VALU, "
               f"{node['valu'] - node['half']} full-rate + {node['half']} half-rate = {2 * (node['valu'] - node['half']) + 4 * node['half']} cycles")
+        if "--json" in sys.argv and tot["bperm"] and "mix" not in locals():  # the first sharing loop = closest-hit walks
+            import json
+            import os
+
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            sys.path.insert(0, root)
+            import vkrt_amd
+
+            mix = {"source_hash": vkrt_amd.source_hash(), "kernel": "k_wf_traverse<false, true, 64, 0>", "loop": "sharing closest-hit walk",
+                   "node_test": {"valu": node["valu"], "half_rate": node["half"]},
+                   "loop_rest": {"valu": tot["valu"] - node["valu"], "half_rate": tot["half"] - node["half"]},
+                   "half_rate_classes": list(HALF_RATE),
+                   "note": "static counts from the assembly (tools/isa_stats.sh + tools/isa_blocks.py --json); a half-rate opcode takes two issue slots "
+                           "of a full-rate one (profiles/r02_issue_microbench.json)"}
+            json.dump(mix, open(os.path.join(root, "profiles", "isa_mix.json"), "w"), indent=1)
         if "--blocks" in sys.argv:
             for b in members:
                 print(f"   {b['name']:>12} valu {b['valu']:3d} mov {b['mov']:2d} salu {b['salu']:2d} lds {b['lds']:2d} mem {b['vmem']} {' '.join(b['br'])}")
