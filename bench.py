@@ -31,6 +31,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) including
                  `frac_calibrated` prices the same rate against the full-rate issue rate tools/issue_microbench.hip sustained
                  (profiles/r02_issue_microbench.json: a pure-VALU load, clock-throttled to 1.5-1.8 GHz; the kernel's own
                  counter pass runs at ~2.3-2.4 GHz, so that figure flatters and is kept only for continuity with round 3).
+                 `issue_mix` (an estimate kept beside `frac`): the ceiling the kernel's opcode mix allows -- a half-rate opcode
+                 takes two issue slots, so a share h of them caps the rate at 1 / (1 + h) of the peak; h from the static opcode classes of the
+                 assembly (profiles/isa_mix.json, tools/isa_blocks.py --json) weighted by this run's dynamic step counts.
                  Sub-blocks, none of them a bound for this kernel: `hbm_own_bytes` (the kernel's own algorithmic bytes --
                  80 B per 8-wide node visited + 48 B per triangle tested + ray / hit records, visit counts from an
                  instrumented launch of this run -- against the 8 TB/s HBM3E peak), `contract` (SURVEY 8d accounting on the
