@@ -452,8 +452,8 @@ def main():
                               "note": "NOT a bound: the node array and most of the triangle array are served by the XCDs' L2s: own bytes against the "
                                       "guide's measured L2 gather rate"},
                 "note": "kernel_ms = mean duration of un-overlapped k_wf_traverse launches (timing pass, one lane); value is measured with the "
-                        "frames of a call in flight.  The kernel is bound by VALU issue (about half of its instructions are half-rate opcodes, so "
-                        "its mix-adjusted ceiling is ~0.65 of the full-rate peak); HBM moves 0.3x the algorithmic bytes (traffic).",
+                        "frames of a call in flight.  The kernel is bound by VALU issue (about 40 % of its instructions are half-rate opcodes: "
+                        "issue_mix prices the ceiling that mix allows); HBM moves 0.3x the algorithmic bytes (traffic).",
             }
             # the binding resource: VALU issue.  Instructions per ray come from a separate --pmc SQ_INSTS_VALU pass (profiles/pmc_issue.json)
             roof = None
