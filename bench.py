@@ -122,6 +122,27 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota():
+    """CPUs the cgroup of this process may use at once (cgroup v2 cpu.max, v1 cpu.cfs_quota_us), rounded up; None = unlimited / unknown."""
+    import math
+
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, math.ceil(int(q) / int(per)))
+        return None
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            return max(1, math.ceil(q / per))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def image_size(n_gpus, base_w, base_h):
     """16:9 image with n_gpus x (base_w x base_h) pixels, width a multiple of 8 (--weak)."""
     if n_gpus <= 1:
@@ -551,7 +572,10 @@ def main():
             frame = args.warmup  # the first timed frame
             pc = make_push_constants(samples=args.spp, depth=args.depth, frame=frame, lights_count=lights)
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            threads = avail  # every hardware thread this process may use (SURVEY 8d "all hardware threads")
+            quota = cpu_quota()  # CPUs the container's cgroup lets this process run at once (None = no limit below the affinity mask)
+            # every hardware thread this process may USE (SURVEY 8d "all hardware threads"): the affinity mask of a 1-GPU box shows all
+            # 256 threads of the host while its cgroup grants ~16 CPUs -- 240 more threads only add context switches
+            threads = max(1, min(avail, quota)) if quota else avail
 
             def sample(nthreads, seconds):
                 """rows of the frame rendered by the oracle for about `seconds` of wall time on `nthreads` threads"""
@@ -560,13 +584,18 @@ def main():
                 tp = time.perf_counter()
                 orc.render(pc, cam, W, H, seed=frame, rows=probe_rows, image=buf, threads=nthreads)
                 per_row = (time.perf_counter() - tp) / len(probe_rows)
-                nrows = int(max(nthreads, min(H, seconds / max(per_row, 1e-6))))
+                # the oracle deals 32-pixel chunks of the rows dynamically: at least 8 chunks per thread, so that no thread's last chunk
+                # is the wall time of the sample
+                min_rows = -(-8 * nthreads // max(1, -(-W // 32)))
+                nrows = int(max(min_rows, 2, min(H, seconds / max(per_row, 1e-6))))
                 for attempt in range(2):  # the probe's first rows run cold and overestimate the row time: rescale once if the sample fell short
                     rows = np.unique(np.linspace(0, H - 1, nrows).astype(np.uint32))
                     buf = np.zeros((len(rows), W, 4), np.float32)
-                    tp = time.perf_counter()
+                    tp, tt = time.perf_counter(), os.times()
                     _, c = orc.render(pc, cam, W, H, seed=frame, rows=rows, image=buf, threads=nthreads)
                     cpu_s = time.perf_counter() - tp
+                    te = os.times()
+                    c["cpu_seconds_per_wall_second"] = ((te.user + te.system) - (tt.user + tt.system)) / max(cpu_s, 1e-9)
                     if cpu_s >= 0.6 * seconds or len(rows) >= H:
                         break
                     nrows = int(min(H, len(rows) * seconds / max(cpu_s, 1e-6)))
@@ -577,7 +606,7 @@ def main():
             cpu_rays = c["rays_closest"] + c["rays_shadow"]
             cpu_rays1 = c1["rays_closest"] + c1["rays_shadow"]
             t16 = None
-            if threads > 16:  # the share of the host a 1-GPU box is sized for (round 1-3 figures were taken on it)
+            if threads != 16 and avail >= 16:  # the share of the host a 1-GPU box is sized for (round 1-3 figures were taken on it)
                 rows16, c16, cpu_s16 = sample(16, 0.5 * args.cpu_seconds)
                 t16 = {"value": (c16["rays_closest"] + c16["rays_shadow"]) / cpu_s16 / 1e6, "unit": "Mrays/s", "cores": 16,
                        "sample": f"{len(rows16)} rows ({c16['rays_closest'] + c16['rays_shadow']} rays, {cpu_s16:.1f} s)"}
@@ -587,7 +616,8 @@ def main():
                           f"full-sweep SAH BVH2 <=4 tris/leaf",
                 "single_thread": {"value": cpu_rays1 / cpu_s1 / 1e6, "unit": "Mrays/s", "cores": 1,
                                   "sample": f"{len(rows1)} rows ({cpu_rays1} rays, {cpu_s1:.1f} s)"},
-                "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "cpus_available_to_this_process": avail,
+                "cpu_seconds_per_wall_second": round(c["cpu_seconds_per_wall_second"], 1),  # CPUs the sample really kept busy
+                "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "cpus_available_to_this_process": avail, "cgroup_cpu_quota": quota,
             }
             if t16:
                 out["cpu_baseline"]["threads_16"] = t16

@@ -155,3 +155,60 @@ def test_issue_mix_estimate_is_the_ceiling_a_share_of_half_rate_opcodes_allows()
     steps = r["per_ray"]["nodes_visited"] / (64.0 * r["per_ray"]["node_step_lane_efficiency"])
     e = bench.issue_mix_block(m, r["valu_wave_instr_per_ray"], steps, r["frac"])
     assert 0.6 < e["ceiling_frac_of_peak"] < 0.8 and r["frac"] < e["frac_of_mix_ceiling"] < 1.0
+
+
+def test_cpu_baseline_threads_deal_chunks_and_agree_with_one_thread():
+    """cpu_baseline (round 5): the oracle deals 32-pixel chunks of the sampled rows to its threads dynamically and every thread counts
+    into a block of its own (VERDICT r04 'weak' 6: whole rows per thread and false-shared counters made 256 threads slower than 16).
+    Pixels and counters must not depend on the thread count, ragged last chunk included; bench.py sizes the sample to at least eight
+    chunks per thread and uses the cgroup's CPU quota when it is below the affinity mask."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import camera_np
+    import oracle_py
+    from vkrt_amd.flat_scene import FlatScene, make_push_constants, uniforms_from_matrices
+
+    flat = FlatScene.load_npz(os.path.join(ROOT, "tests", "golden", "cornell_flat.npz"))
+    W, H = 75, 40  # 75 = two whole chunks + a ragged one of 11 pixels
+    cam = uniforms_from_matrices(*camera_np.global_uniforms(width=W, height=H))
+    pc = make_push_constants(samples=2, depth=3, frame=0, lights_count=len(flat.lights))
+    orc = oracle_py.OracleScene(flat)
+    rows = np.array([0, 7, 8, 21, 39], np.uint32)
+    ref, c1 = orc.render(pc, cam, W, H, seed=3, rows=rows, threads=1)
+    for nt in (3, 16, 61):
+        img, c = orc.render(pc, cam, W, H, seed=3, rows=rows, threads=nt)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and c == c1, nt
+    assert c1["pixels"] == len(rows) * W and c1["rays_closest"] > 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "min_rows = -(-8 * nthreads" in src and "cpu_quota()" in src and '"cgroup_cpu_quota": quota' in src
+    osrc = open(os.path.join(ROOT, "oracle", "oracle.cpp")).read()
+    assert "std::vector<Counters> cs(nt);" in osrc and "Counters c;\n    for(;;)" in osrc  # thread-local block, handed over once
+
+
+def test_cpu_quota_reads_cgroup_files(tmp_path, monkeypatch):
+    import builtins
+
+    import bench
+
+    real_open = builtins.open
+
+    def fake(files):
+        def _open(path, *a, **k):
+            if isinstance(path, str) and path.startswith("/sys/fs/cgroup/"):
+                if path in files:
+                    f = tmp_path / path.replace("/", "_")
+                    f.write_text(files[path])
+                    return real_open(f, *a, **k)
+                raise FileNotFoundError(path)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}))
+    assert bench.cpu_quota() == 16
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "max 100000\n"}))
+    assert bench.cpu_quota() is None
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "250000\n", "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}))
+    assert bench.cpu_quota() == 3
+    monkeypatch.setattr(builtins, "open", fake({}))
+    assert bench.cpu_quota() is None

@@ -59,7 +59,34 @@
   _(44, "v_cvt_f32_f16",        1, "v_cvt_f32_f16 %0, %1") \
   _(45, "v_cvt_u32_f32",        1, "v_cvt_u32_f32 %1, %0") \
   _(46, "v_ldexp_f32",          1, "v_ldexp_f32 %0, %0, %3") \
-  _(47, "v_fma_mix_f32",        1, "v_fma_mix_f32 %0, %0, %3, %4")
+  _(47, "v_fma_mix_f32",        1, "v_fma_mix_f32 %0, %0, %3, %4") \
+  _(48, "v_pk_fma_f16",         1, "v_pk_fma_f16 %1, %1, %3, %4") \
+  _(49, "v_pk_mul_f16",         1, "v_pk_mul_f16 %1, %1, %3") \
+  _(50, "v_pk_add_f16",         1, "v_pk_add_f16 %1, %1, %3") \
+  _(51, "v_pk_max_f16",         1, "v_pk_max_f16 %1, %1, %3") \
+  _(52, "v_pk_min_f16",         1, "v_pk_min_f16 %1, %1, %3") \
+  _(53, "v_pk_maximum3_f16",    1, "v_pk_maximum3_f16 %1, %1, %3, %4") \
+  _(54, "v_pk_minimum3_f16",    1, "v_pk_minimum3_f16 %1, %1, %3, %4") \
+  _(55, "v_maximum3_f32",       1, "v_maximum3_f32 %0, %0, %3, %4") \
+  _(56, "v_minimum3_f32",       1, "v_minimum3_f32 %0, %0, %3, %4") \
+  _(57, "v_pk_lshrrev_b16",     1, "v_pk_lshrrev_b16 %1, 8, %1") \
+  _(58, "v_pk_ashrrev_i16",     1, "v_pk_ashrrev_i16 %1, 15, %1") \
+  _(59, "v_pk_mad_u16",         1, "v_pk_mad_u16 %1, %1, %3, %4") \
+  _(60, "v_pk_max_u16",         1, "v_pk_max_u16 %1, %1, %3") \
+  _(61, "v_pk_sub_i16",         1, "v_pk_sub_i16 %1, %1, %3") \
+  _(62, "v_pk_add_u16",         1, "v_pk_add_u16 %1, %1, %3") \
+  _(63, "v_bfe_i32",            1, "v_bfe_i32 %1, %1, 15, 1") \
+  _(64, "v_ashrrev_i32",        1, "v_ashrrev_i32 %1, 31, %1") \
+  _(65, "v_cvt_pkrtz_f16_f32",  1, "v_cvt_pkrtz_f16_f32 %1, %0, %3") \
+  _(66, "v_cvt_pk_f16_f32",     1, "v_cvt_pk_f16_f32 %1, %0, %3") \
+  _(67, "v_pk_fma_f16_denormal_operands", 1, "v_pk_fma_f16 %1, %1, %1, %1") \
+  _(68, "v_cmp_lt_i16",         1, "v_cmp_lt_i16 %2, %1, %3") \
+  _(69, "v_lshlrev_b32_imm",    1, "v_lshlrev_b32 %1, 16, %1") \
+  _(70, "v_and_b32_literal",    1, "v_and_b32 %1, 0x00ff00ff, %1") \
+  _(71, "v_sub_u32",            1, "v_sub_u32 %1, %1, %3") \
+  _(72, "v_dot4_u32_u8",        1, "v_dot4_u32_u8 %1, %1, %3, %4") \
+  _(73, "v_cvt_f16_f32",        1, "v_cvt_f16_f32 %1, %0") \
+  _(74, "v_pk_fma_f16_opsel",   1, "v_pk_fma_f16 %1, %1, %3, %4 op_sel:[0,1,0] op_sel_hi:[1,0,1]")
 // clang-format on
 template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, unsigned long long* cyc, float s)
 {
@@ -68,6 +95,7 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, uns
   for(int i = 0; i < 8; i++) { v[i] = s + threadIdx.x + i; u[i] = threadIdx.x * 2654435761u + i; }
   for(int i = 0; i < 4; i++) { p[i] = s + i; q[i] = s * 0.25 + i; }
   const float a = s * 0.5f, b = s + 0.25f;
+  if(OP == 67) for(int i = 0; i < 8; i++) u[i] &= 0x00ff00ffu;  // binary16 subnormals in both halves: x * x + x stays subnormal
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
   for(int it = 0; it < ITERS; it++)
   {
@@ -78,7 +106,7 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, uns
   if(OP == id)                                                                                                                        \
   {                                                                                                                                   \
     _Pragma("unroll") for(int i = 0; i < 8; i++)                                                                                      \
-      if(id == 13 || id == 14)                                                                                                          \
+      if(id == 13 || id == 14 || id == 68)                                                                                              \
         asm volatile(text : "+v"(v[i]), "+v"(u[i]), "=s"(m[i]) : "v"(a), "v"(b));                                                     \
       else if(id == 26 || id == 27) /* the 64-bit pair stream only where it is used (declared pair writes get s_nop padding) */        \
         asm volatile(text : "+v"(v[i]), "+v"(u[i]), "+v"(p[i & 3]) : "v"(a), "v"(b), "v"(q[i & 3]));                                   \
@@ -90,7 +118,7 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, uns
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-  float acc = 0; for(int i = 0; i < 8; i++) acc += v[i] + (float)u[i] + (float)p[i & 3] + ((OP == 13 || OP == 14) ? (float)m[i] : 0.0f);
+  float acc = 0; for(int i = 0; i < 8; i++) acc += v[i] + (float)u[i] + (float)p[i & 3] + ((OP == 13 || OP == 14 || OP == 68) ? (float)m[i] : 0.0f);
   out[blockIdx.x * 256 + threadIdx.x] = acc + (float)pin[0];
   if((threadIdx.x & 63) == 0)
   {
@@ -133,7 +161,7 @@ template <int OP> static void run(const char* name, int perBody, bool last)
 int main()
 {
   printf("{\n \"note\": \"per opcode: waves/SIMD -> chip-wide G wave64-instructions/s (in-kernel stamps; hipEvent), shader clock, cycles per instruction per SIMD\",\n");
-#define RUN(id, name, n, text) run<id>(name, n, id == 47);
+#define RUN(id, name, n, text) run<id>(name, n, id == 74);
   OPS(RUN)
   printf("}\n");
   return 0;
