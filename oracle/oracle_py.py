@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(_HERE))
 import vkrt_amd  # noqa: E402,F401
 from vkrt_amd import abi  # noqa: E402
 
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # ORACLE_LIB: the sanitizer build (tests/test_host_asan.py)
 _lib = None
 
 

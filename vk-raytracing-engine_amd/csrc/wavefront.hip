@@ -493,14 +493,7 @@ static void subframeRound(const TraceParams& P, const WfBuffers& B, int r, unsig
   const unsigned work = P.tileCount * 64u;
   // every path holds one record and a record at most two rays; +4 blocks for the partial tails of the four ray kinds.
   // One wavefront per workgroup by default: a finished wave frees its slot and LDS without waiting for three others.
-#ifdef VKRT_GRID_STRIDE
-  static const unsigned gridPct = getenv("VKRT_TRAV_GRID_PCT") ? (unsigned)atoi(getenv("VKRT_TRAV_GRID_PCT")) : 100u;
-  static const unsigned gridAbs = getenv("VKRT_TRAV_GRID_ABS") ? (unsigned)atoi(getenv("VKRT_TRAV_GRID_ABS")) : 0u;
-  const unsigned worst = 2 * ((work + travBlock - 1) / travBlock) + 4;
-  const dim3 tg(gridAbs ? std::min(worst, gridAbs) : std::max(1u, (unsigned)((uint64_t)worst * gridPct / 100u)));
-#else
   const dim3 tg(2 * ((work + travBlock - 1) / travBlock) + 4);
-#endif
   const size_t tlds = (size_t)P.sc.stackCap * travBlock * sizeof(int);
   const bool timed = timing && timing->events && 2 * (timing->used + 1) <= timing->capacity;
   if(timed)

@@ -64,13 +64,7 @@ void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
   }
   // block ranges: [closest rays of C][closest rays of P][shadow rays of S][shadow rays of P]
   const unsigned nC = (cC + TB - 1) / TB, nP = (cP + TB - 1) / TB, nS = (cS + TB - 1) / TB;
-#ifdef VKRT_GRID_STRIDE
-  for(unsigned b0 = blockIdx.x;; b0 += gridDim.x)
-  {
-  unsigned blk = b0;
-#else
   unsigned blk = blockIdx.x;
-#endif
   int kind;
   unsigned count;
   if(blk < nC) { kind = WF_K_CLOSEST_C; count = cC; }
@@ -121,10 +115,6 @@ void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
     const unsigned vals[10] = {0, 0, 0, 0, 0, 0, tc.nodes, tc.tris, tc.waveNodeSteps, tc.waveTriSteps};
     blockAddCounters(&P.counters->v[blockIdx.x % VKRT_COUNTER_SLOTS][0], vals, 10, red);
   }
-#ifdef VKRT_GRID_STRIDE
-  __syncthreads();
-  }
-#endif
 }
 
 // One traversal launch: the instantiation for (instrumented?, node layout, workgroup size, triangle mode).  The non-default triangle

@@ -72,6 +72,15 @@ private:
   {
     const std::string& s;
     size_t i;
+    int depth = 0;  // open containers around the value being parsed: recursion is bounded (a file of 100 k '[' overflowed the stack;
+                    // found by the sanitizer build, tests/test_host_asan.py).  glTF needs a dozen levels; tinygltf's json.hpp has a limit too
+    static constexpr int kMaxDepth = 192;
+    struct Nest
+    {
+      Parser& p;
+      explicit Nest(Parser& q) : p(q) { if(++p.depth > kMaxDepth) p.err("nesting too deep"); }
+      ~Nest() { p.depth--; }
+    };
     [[noreturn]] void err(const char* m) { throw std::runtime_error(std::string("json: ") + m + " at offset " + std::to_string(i)); }
     void ws()
     {
@@ -92,6 +101,7 @@ private:
       const char c = s[i];
       if(c == '{')
       {
+        const Nest nest(*this);
         j.type = Object;
         i++;
         ws();
@@ -114,6 +124,7 @@ private:
       }
       else if(c == '[')
       {
+        const Nest nest(*this);
         j.type = Array;
         i++;
         ws();
