@@ -303,9 +303,8 @@ def main():
     rows_local = r.shard_rows(shard)
     image = torch.zeros((rows_local, W, 4), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    r.reserve(shard, stream)  # no allocation / host synchronisation inside the timed launches
-
     per_call = max(1, args.frames_per_call)
+    r.reserve(shard, stream, frames_per_call=per_call)  # no allocation / host synchronisation inside the timed launches
 
     def render(first_frame, n=1, flags=0, rr=None, sh=None, img=None):
         """n progressive frames from `first_frame` on: one vkrt_pathtrace (n = 1) or one vkrt_pathtrace_frames call"""
@@ -360,7 +359,7 @@ def main():
 
     # ---- untimed extra passes: per-kernel durations (HIP events around every traversal launch) and the kernel's own
     #      work counters (instrumented launch) ---------------------------------------------------------------------------
-    frame_ms, trav_ms, trav_launches = [], [], []
+    frame_ms, trav_ms, trav_launches, shade_launch_ms = [], [], [], []
     next_frame = args.warmup + args.steps
     for k in range(min(args.steps, 3)):
         step(next_frame + k, flags=abi.VKRT_TRACE_TIME_KERNELS)
@@ -369,6 +368,8 @@ def main():
         frame_ms.append(tm["total_ms"])
         trav_ms.append(tm["traverse_ms"])
         trav_launches.append(tm["traverse_launches"])
+        if tm["shade_launches"]:
+            shade_launch_ms.append(tm["shade_ms"] / tm["shade_launches"])
     mode = tm["mode"]
     r.reset_counters(stream)
     step(next_frame + 3, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL)
@@ -524,6 +525,39 @@ def main():
                                           "achieved": tg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tg / HBM_PEAK_GBS, "pmc_stale": tstale,
                                           "over_algorithmic_bytes": roof["traffic"] / own,
                                           "source": "profiles/pmc_traffic.json (FETCH_SIZE / WRITE_SIZE passes, reads x2 per the guide's gfx950 note)"}
+            # ---- the second kernel of the frame: k_wf_shade (raytrace.rchit / .rmiss, rgen:79-120).  What it moves: path records in and
+            # out (sequential, counted from the stream counts) + the hit shader's gathers; priced against the HBM peak with the fabric-side
+            # bytes of the separate --pmc FETCH_SIZE / WRITE_SIZE passes, raw and with the guide's x2 on the read side
+            if shade_launch_ms and pm and "k_wf_shade" in pm.get("kernels", {}) and "read_bytes_per_ray_raw" in pm["kernels"]["k_wf_shade"]:
+                sk = pm["kernels"]["k_wf_shade"]
+                s_ms = float(np.mean(shade_launch_ms))
+                rd, wr = sk["read_bytes_per_ray_raw"] * rays_launch, sk["write_bytes_per_ray"] * rays_launch
+                nP = cnt.get("pair_records", 0) / args.steps
+                nC, nS = cnt["rays_closest"] / args.steps - nP, cnt["rays_shadow"] / args.steps - nP
+                rec_in = (96 * nC + 80 * nS + 112 * nP) / n_l
+                rec_out = (80 * max(nC - cnt["pixels"] / args.steps, 0.0) + 96 * nS + 112 * nP + 16 * cnt["pixels"] / args.steps) / n_l
+                g = lambda b: b / (s_ms * 1e-3) / 1e9
+                roof["shade"] = {
+                    "kernel": "k_wf_shade", "bound": "hbm", "kernel_ms": s_ms, "records_per_launch": (nC + nS + nP) / n_l,
+                    "achieved": g(rd + wr), "achieved_reads_x2": g(2 * rd + wr), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": g(rd + wr) / HBM_PEAK_GBS, "frac_reads_x2": g(2 * rd + wr) / HBM_PEAK_GBS,
+                    "traffic": rd + wr, "traffic_reads_x2": 2 * rd + wr, "read_bytes_per_launch_raw": rd, "write_bytes_per_launch": wr,
+                    "record_bytes_in_per_launch": rec_in, "record_bytes_out_per_launch": rec_out,
+                    "record_GBs": g(rec_in + rec_out), "record_frac": g(rec_in + rec_out) / HBM_PEAK_GBS, "pmc_stale": tstale,
+                    "note": "kernel_ms = mean time between the end of a traversal launch and the start of the next one in the timing pass (one lane): "
+                            "the k_wf_shade launch between them plus the launch gaps.  record bytes: 96 / 80 / 112 B read and 80 / 96 / 112 B written per "
+                            "closest / shadow / pair record (wf_streams.h), counts from the stream counters of the timed region; traffic: "
+                            "profiles/pmc_traffic.json per ray x rays per launch of this run (fabric side of L2, Infinity-Cache hits included)"}
+                fr = pm.get("frame")
+                if fr:
+                    fb_raw = (fr["read_bytes_per_ray_raw"] + fr["write_bytes_per_ray"]) * rays_frame
+                    fb_x2 = (2 * fr["read_bytes_per_ray_raw"] + fr["write_bytes_per_ray"]) * rays_frame
+                    step_s = elapsed / args.steps
+                    roof["frame_hbm"] = {"achieved": fb_raw / step_s / 1e9, "achieved_reads_x2": fb_x2 / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": fb_raw / step_s / 1e9 / HBM_PEAK_GBS, "frac_reads_x2": fb_x2 / step_s / 1e9 / HBM_PEAK_GBS,
+                                         "bytes_per_frame_raw": fb_raw, "pmc_stale": tstale,
+                                         "note": "achieved HBM GB/s of the whole frame (north star): FETCH_SIZE + WRITE_SIZE of every kernel of the frame per ray "
+                                                 "(separate --pmc passes) x the rays of a timed step / ms_per_step; reads raw and x2 (guide's gfx950 correction)"}
             out["roofline"] = roof
         elif frame_ms:
             own = (64 * work["nodes_visited"] + 48 * work["tris_tested"]) if work["nodes_visited"] else 0

@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define VKRT_ABI_VERSION 3 /* 2: vkrt_scene_set_option / vkrt_reserve, vkrt_counters.traversal_faults.
+#define VKRT_ABI_VERSION 4 /* 4: vkrt_reserve_frames; vkrt_counters.pair_records, vkrt_trace_timing.shade_ms / shade_launches (appended).
+                              2: vkrt_scene_set_option / vkrt_reserve, vkrt_counters.traversal_faults.
                               3: vkrt_pathtrace_frames, VKRT_TRACE_SAME_SEED_EVERY_FRAME, options 10-14, vkrt_accel_info.reference_count,
                                  vkrt_accel_check.triangles_uncovered, VKRT_INFO_ANYHIT_ORDER (the options and the query
                                  that round 3 had added under version 2 are part of 3: a client that needs them asks for >= 3) */
@@ -167,6 +168,8 @@ typedef struct vkrt_counters {
   uint64_t wave_tri_steps;  /* same for the triangle phase                        */
   uint64_t traversal_faults; /* always counted: stack pushes dropped (stack sized from the builder's depth) + walks cut by the step
                                bound.  Non-zero means a builder / traversal mismatch and possibly wrong pixels; tests assert 0. */
+  uint64_t pair_records;   /* ABI 4, wavefront pipeline: path records that carried TWO rays through a round (the shadow ray of a segment and
+                              the closest-hit ray of the next one): records moved = rays_closest + rays_shadow - pair_records */
 } vkrt_counters;
 
 typedef struct vkrt_accel_info {
@@ -269,6 +272,17 @@ uint32_t vkrt_shard_rows(const vkrt_shard* shard); /* rows of the shard's buffer
  * shard never allocates and never synchronises with the host.  Without it the first launch (and any launch larger
  * than every earlier one) grows the working set lazily: one hipStreamSynchronize + hipMalloc inside that call. */
 int vkrt_reserve(vkrt_scene* scene, const vkrt_shard* shard, void* hip_stream);
+/* The same for a caller that knows how many frames it hands to one vkrt_pathtrace_frames call (ABI 4).  The working set holds one
+ * set of path-record streams (544 B per pixel of the shard) per frame the library keeps in flight inside a call, plus a 16-B staging
+ * plane per pixel and frame in flight: frames_per_call = 1 (a client of vkrt_pathtrace only) sizes it for ONE set -- 1.1 GB at
+ * 1920x1080, 4.5 GB at 3840x2160 --, frames_per_call >= VKRT_OPT_WF_FRAMES_IN_FLIGHT (default 3) for that many: 3.5 GB / 14 GB.
+ * vkrt_reserve is vkrt_reserve_frames with frames_per_call = VKRT_OPT_WF_FRAMES_IN_FLIGHT, i.e. the larger figure whatever the
+ * client goes on to call.  The working set only grows (a later, larger call or reservation re-allocates it once); it is released by
+ * vkrt_scene_destroy.  Texture memory, for the record: vkrt_scene_create keeps, beside the RGBA8 pool with its mip chain (4/3 of the
+ * texel bytes), a footprint pool of 16 B per level-0 texel -- 4x the level-0 texel bytes -- so that a bilinear tap of the path tracer
+ * is one load; it is built while it stays under 2 GiB (above that, and with the test hook VKRT_TEX_QUADS=0 in the environment, taps
+ * gather their four texels from the RGBA8 pool: same values, ~9 % slower hit shading). */
+int vkrt_reserve_frames(vkrt_scene* scene, const vkrt_shard* shard, uint32_t frames_per_call, void* hip_stream);
 /* Asynchronous like the command-buffer recording it replaces: returns after enqueueing.  All work is ordered after what
  * was enqueued on `hip_stream` before the call and complete before anything enqueued on it afterwards (the library may
  * run parts of a frame on internal streams that fork from and join `hip_stream` through events).  No host
@@ -287,7 +301,8 @@ int vkrt_pathtrace(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUni
  * launches of one frame fill the tails of the other's, which a sequence of single-frame calls -- each complete before the next
  * begins -- cannot do.  Same asynchrony, ordering and
  * shard rules as vkrt_pathtrace (which is this call with n_frames = 1); vkrt_counters and vkrt_last_trace_ms cover the whole call.
- * Working set: vkrt_reserve sizes it for the frames the current options keep in flight. */
+ * Working set: vkrt_reserve_frames(scene, shard, n_frames, stream) sizes it for such calls (vkrt_reserve: for whatever the current
+ * options keep in flight). */
 int vkrt_pathtrace_frames(vkrt_scene* scene, const PushConstantRay* pc, const GlobalUniforms* cam,
                           const vkrt_trace_opts* opts, const vkrt_shard* shard,
                           float* rgba32f_device, uint32_t n_frames, void* hip_stream);
@@ -361,6 +376,9 @@ typedef struct vkrt_trace_timing {
   float    traverse_ms;
   uint32_t traverse_launches;
   uint32_t mode;            /* 1 wavefront pipeline, 0 megakernel (VKRT_MODE=mega) */
+  float    shade_ms;        /* ABI 4, with VKRT_TRACE_TIME_KERNELS: summed time between the end of a traversal launch and the start of the
+                               next one of the same frame = the k_wf_shade launch between them (and the launch gap on either side) */
+  uint32_t shade_launches;  /* the shade launches shade_ms covers (the last one of each frame is not bracketed and not counted) */
 } vkrt_trace_timing;
 int vkrt_last_trace_timing(vkrt_scene* scene, vkrt_trace_timing* out);
 

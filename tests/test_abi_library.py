@@ -67,7 +67,7 @@ def test_argument_validation_and_no_cpu_fallback(cornell_flat):
     assert (abi.VKRT_OPT_WATERTIGHT, abi.VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, abi.VKRT_OPT_ANYHIT_DISSOLVE) == (10, 11, 12)
     hdr = open(os.path.join(ROOT, "include", "vkrt.h")).read()
     assert (abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT, abi.VKRT_OPT_SPLIT_BUDGET) == (13, 14)
-    assert "VKRT_OPT_LAST            = 14" in hdr and "#define VKRT_ABI_VERSION 3" in hdr and abi.VKRT_ABI_VERSION == 3
+    assert "VKRT_OPT_LAST            = 14" in hdr and "#define VKRT_ABI_VERSION 4" in hdr and abi.VKRT_ABI_VERSION == 4
     desc, keep = cornell_flat.to_desc()
     if lib.vkrt_device_count() == 0:
         # the product never computes on the CPU: without a device creation must fail loudly

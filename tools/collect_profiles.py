@@ -82,6 +82,19 @@ if dom:
     out["write_bytes_per_launch"] = out["kernels"][dom]["write_bytes_per_launch"]
     tie(out, "pmc_fetch.log", [("hbm_bytes_per_launch", "hbm_bytes_per_ray"), ("read_bytes_per_launch_raw", "read_bytes_per_ray_raw"),
                                ("write_bytes_per_launch", "write_bytes_per_ray")])
+# per-ray figures of every kernel of the frame and of the frame as a whole (bench.py: roofline.shade, roofline.frame_hbm): bytes of
+# all launches of a kernel over the rays of all traversal launches of the same pass
+if dom and "rays_per_launch" in out:
+    rounds = sum(v["launches_profiled"] for k, v in out["kernels"].items() if "traverse" in k)
+    rays = out["rays_per_launch"] * max(rounds, 1)
+    fr = {"read_bytes_per_ray_raw": 0.0, "write_bytes_per_ray": 0.0}
+    for k, v in out["kernels"].items():
+        v["read_bytes_per_ray_raw"] = v["read_bytes_per_launch_raw"] * v["launches_profiled"] / rays
+        v["write_bytes_per_ray"] = v["write_bytes_per_launch"] * v["launches_profiled"] / rays
+        v["launches_per_round"] = v["launches_profiled"] / max(rounds, 1)
+        fr["read_bytes_per_ray_raw"] += v["read_bytes_per_ray_raw"]
+        fr["write_bytes_per_ray"] += v["write_bytes_per_ray"]
+    out["frame"] = fr
 json.dump(out, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
 # VALU issue rate of the dominant kernel (the resource that actually binds it): wave-instructions per launch
 if glob.glob(os.path.join(src, "pmc_valu", "*", "*counter_collection.csv")):

@@ -78,7 +78,10 @@ def main():
             sys.path.insert(0, root)
             import vkrt_amd
 
-            mix = {"source_hash": vkrt_amd.source_hash(), "kernel": "k_wf_traverse<false, true, 64, 0>", "loop": "sharing closest-hit walk",
+            import subprocess
+            hv = re.search(r"HIP version:\s*(\S+)", subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout)
+            mix = {"source_hash": vkrt_amd.source_hash(), "hipcc": hv.group(1) if hv else "unknown",
+                   "kernel": "k_wf_traverse<false, true, 64, 0>", "loop": "sharing closest-hit walk",
                    "node_test": {"valu": node["valu"], "half_rate": node["half"]},
                    "loop_rest": {"valu": tot["valu"] - node["valu"], "half_rate": tot["half"] - node["half"]},
                    "half_rate_classes": list(HALF_RATE),

@@ -17,7 +17,20 @@ kind = os.environ.get("BUILD", "ploc")
 extra = {int(k): int(v) for k, v in (kv.split("=") for kv in os.environ.get("PROBE_OPTS", "").split(",") if kv)}
 for variant in os.environ.get("PROBE_VARIANTS", "default;nonuniform").split(";"):
     flat, info = atrium.build_atrium(262144, seed=1, **({} if variant == "default" else {"variant": variant}))
-    cam = host_py.global_uniforms(width=W, height=H, **atrium.DEFAULT_CAMERA)
+    camkw = dict(atrium.DEFAULT_CAMERA)
+    if os.environ.get("PROBE_ROTATE"):
+        # the whole building turned about y and tilted about x (degrees "ry,rx"): no large triangle is aligned with the axes any more, which
+        # is where reference splitting is known to pay (the boxes of room-sized diagonal triangles are mostly empty).  Lights stay put.
+        import numpy as np
+        ry, rx = (float(v) * np.pi / 180.0 for v in (os.environ["PROBE_ROTATE"].split(",") + ["0"])[:2])
+        Ry = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+        R4 = np.eye(4); R4[:3, :3] = Rx @ Ry
+        wm = flat.nodes["worldMatrix"].reshape(-1, 4, 4).astype(np.float64)  # column-major: stored matrix = M^T
+        flat.nodes["worldMatrix"] = np.einsum("nij,jk->nik", wm, R4.T).reshape(flat.nodes["worldMatrix"].shape).astype(np.float32)
+        for key in ("eye", "center", "up"):
+            camkw[key] = tuple((R4[:3, :3] @ np.asarray(camkw[key], np.float64)).tolist())
+    cam = host_py.global_uniforms(width=W, height=H, **camkw)
     r = Renderer(flat, device=0, build=None)
     for budget in [int(b) for b in os.environ.get("PROBE_BUDGETS", "0,10,20,30,50").split(",")]:
         r.set_option(abi.VKRT_OPT_SPLIT_BUDGET, budget)
@@ -43,7 +56,7 @@ for variant in os.environ.get("PROBE_VARIANTS", "default;nonuniform").split(";")
         r.pathtrace(make_push_constants(samples=4, depth=8, frame=1, lights_count=8), cam, W, H, seed=1, flags=abi.VKRT_TRACE_COUNT_TRAVERSAL, image=img)
         w = r.counters()
         wr = w["rays_closest"] + w["rays_shadow"]
-        print(json.dumps({"variant": variant, "build": kind, "budget": budget, "opts": extra, "ms_per_frame": round(best, 3), "Mrays_s": round(rays / best / 1e3, 1),
+        print(json.dumps({"variant": variant, "rotate": os.environ.get("PROBE_ROTATE", ""), "build": kind, "budget": budget, "opts": extra, "ms_per_frame": round(best, 3), "Mrays_s": round(rays / best / 1e3, 1),
                           "nodes_per_ray": round(w["nodes_visited"] / wr, 2), "tris_per_ray": round(w["tris_tested"] / wr, 2),
                           "node_lane_eff": round(w["nodes_visited"] / max(64 * w["wave_node_steps"], 1), 3), "tri_lane_eff": round(w["tris_tested"] / max(64 * w["wave_tri_steps"], 1), 3),
                           "wave_node_steps_per_kray": round(1e3 * w["wave_node_steps"] / wr, 2), "wave_tri_steps_per_kray": round(1e3 * w["wave_tri_steps"] / wr, 2),

@@ -129,6 +129,7 @@ class Counters(C.Structure):
         ("wave_node_steps", c_u64),
         ("wave_tri_steps", c_u64),
         ("traversal_faults", c_u64),
+        ("pair_records", c_u64),
     ]
 
     def as_dict(self):
@@ -163,7 +164,7 @@ class PushConstantPost(C.Structure):
 
 
 class TraceTiming(C.Structure):
-    _fields_ = [("total_ms", c_f), ("traverse_ms", c_f), ("traverse_launches", c_u), ("mode", c_u)]
+    _fields_ = [("total_ms", c_f), ("traverse_ms", c_f), ("traverse_launches", c_u), ("mode", c_u), ("shade_ms", c_f), ("shade_launches", c_u)]
 
 
 # layout contract
@@ -183,7 +184,7 @@ VKRT_TRACE_SEED_INDEX_ROW_MAJOR = 0x1
 VKRT_TRACE_COUNT_TRAVERSAL = 0x2
 VKRT_TRACE_TIME_KERNELS = 0x4
 VKRT_TRACE_SAME_SEED_EVERY_FRAME = 0x8
-VKRT_ABI_VERSION = 3
+VKRT_ABI_VERSION = 4
 # vkrt_option
 VKRT_OPT_MODE, VKRT_OPT_BVH_LAYOUT, VKRT_OPT_WF_SUBFRAMES, VKRT_OPT_WF_TRAV_BLOCK = 1, 2, 3, 4
 VKRT_OPT_WF_SHARE, VKRT_OPT_TRI_THRESHOLD, VKRT_OPT_WF_SHARE_PERIOD, VKRT_OPT_WF_SHARE_FLAGS = 5, 6, 7, 8
@@ -202,6 +203,7 @@ VKRT_SYMBOLS = [
     "vkrt_scene_set_option",
     "vkrt_scene_get_option",
     "vkrt_reserve",
+    "vkrt_reserve_frames",
     "vkrt_accel_build",
     "vkrt_accel_get_info",
     "vkrt_shard_rows",
@@ -238,6 +240,8 @@ def declare_vkrt(lib):
     lib.vkrt_scene_get_option.restype = C.c_int
     lib.vkrt_reserve.argtypes = [C.c_void_p, P(Shard), C.c_void_p]
     lib.vkrt_reserve.restype = C.c_int
+    lib.vkrt_reserve_frames.argtypes = [C.c_void_p, P(Shard), C.c_uint32, C.c_void_p]
+    lib.vkrt_reserve_frames.restype = C.c_int
     lib.vkrt_accel_build.argtypes = [C.c_void_p, c_u, C.c_void_p]
     lib.vkrt_accel_build.restype = C.c_int
     lib.vkrt_accel_get_info.argtypes = [C.c_void_p, P(AccelInfo)]

@@ -532,9 +532,13 @@ VKRT_DEV bool splitClip(const SplitTri& t, const float* b, int axis, float pos, 
 }
 
 // The pieces of triangle g for a budget of s splits, depth first with the smaller share first (stack depth <= log2(s) + 2).
-// EMIT: writes (g, box) of every piece from slot `base` on.  Returns the number of pieces (1 .. s + 1); the same for both EMIT values.
+// EMIT: writes (g, box) of every piece from slot `base` on.  Returns the number of pieces (1 .. s + 1); the same for both EMIT values
+// -- they are two instantiations of one routine, and the emitting one is additionally held to the `limit` slots the counting one
+// claimed for this triangle: a piece beyond them is merged into the last slot (box union) and slots left over repeat the last piece, so
+// that a divergence of the two (code generation, contraction) could cost tree quality but never write into a neighbour's slots or
+// leave a slot unwritten.
 template <bool EMIT>
-VKRT_DEV unsigned splitTriangle(const SplitGrid& G, const SplitTri& t, unsigned s, unsigned g, unsigned base, unsigned* refTri, float* refBox)
+VKRT_DEV unsigned splitTriangle(const SplitGrid& G, const SplitTri& t, unsigned s, unsigned g, unsigned base, unsigned limit, unsigned* refTri, float* refBox)
 {
   struct Item { float b[6]; unsigned s; };
   Item stack[VKRT_SPLIT_STACK];
@@ -578,13 +582,26 @@ VKRT_DEV unsigned splitTriangle(const SplitGrid& G, const SplitTri& t, unsigned 
     {
       if(EMIT)
       {
-        refTri[base + n] = g;
         const float pad = t.slop;
-#pragma unroll
-        for(int k = 0; k < 3; k++)
+        if(n < limit)
         {
-          refBox[6 * (size_t)(base + n) + k] = fmaxf(it.b[k] - pad, t.full[k]);
-          refBox[6 * (size_t)(base + n) + 3 + k] = fminf(it.b[3 + k] + pad, t.full[3 + k]);
+          refTri[base + n] = g;
+#pragma unroll
+          for(int k = 0; k < 3; k++)
+          {
+            refBox[6 * (size_t)(base + n) + k] = fmaxf(it.b[k] - pad, t.full[k]);
+            refBox[6 * (size_t)(base + n) + 3 + k] = fminf(it.b[3 + k] + pad, t.full[3 + k]);
+          }
+        }
+        else if(limit > 0u)
+        {
+          float* last = refBox + 6 * (size_t)(base + limit - 1u);
+#pragma unroll
+          for(int k = 0; k < 3; k++)
+          {
+            last[k] = fminf(last[k], fmaxf(it.b[k] - pad, t.full[k]));
+            last[3 + k] = fmaxf(last[3 + k], fminf(it.b[3 + k] + pad, t.full[3 + k]));
+          }
         }
       }
       n++;
@@ -602,6 +619,12 @@ VKRT_DEV unsigned splitTriangle(const SplitGrid& G, const SplitTri& t, unsigned 
     if(sa >= sb) { stack[sp++] = A; stack[sp++] = B; }  // the smaller share is taken first
     else { stack[sp++] = B; stack[sp++] = A; }
   }
+  if(EMIT && n > 0u)
+    for(unsigned k = min(n, limit); k < limit; k++)  // (never taken while the two instantiations agree)
+    {
+      refTri[base + k] = g;
+      for(int c = 0; c < 6; c++) refBox[6 * (size_t)(base + k) + c] = refBox[6 * (size_t)(base + min(n, limit) - 1u) + c];
+    }
   return n;
 }
 
@@ -683,9 +706,9 @@ __global__ void k_split_refs(unsigned T, const float4* __restrict__ triU, const 
   loadSplitTri(triU, triBox, g, watertight, t);
   const unsigned s = min((unsigned)(*D * prio[g]), VKRT_SPLIT_MAX_PER_TRI);
   if(EMIT)
-    (void)splitTriangle<true>(G, t, s, g, counts[g], refTri, refBox);
+    (void)splitTriangle<true>(G, t, s, g, counts[g], counts[g + 1] - counts[g], refTri, refBox);  // counts = exclusive offsets, T + 1 entries
   else
-    counts[g] = splitTriangle<false>(G, t, s, g, 0u, nullptr, nullptr);
+    counts[g] = splitTriangle<false>(G, t, s, g, 0u, 0u, nullptr, nullptr);
 }
 
 // ---- SAH top of the tree ------------------------------------------------------------------------------------------------

@@ -56,6 +56,9 @@ VKRT_DEV void w8_begin(const DevScene& sc, W8State<TM>& S, f3 o, f3 d, float tma
 // compiler emits v_bfe_u32 + v_lshrrev_b32 + v_lshlrev_b32 -- eight times per node test (profiles/r04_experiments.md #127)
 VKRT_DEV unsigned w8_piece(unsigned idx4, unsigned bits4, int k)
 {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+  return ((bits4 >> (8 * k)) & 0xffu) << ((idx4 >> (8 * k)) & 31u);  // (SDWA is a GFX9 encoding; the library is built for gfx950)
+#else
   unsigned r;
   if(k == 0)
     asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(idx4), "v"(bits4));
@@ -66,6 +69,7 @@ VKRT_DEV unsigned w8_piece(unsigned idx4, unsigned bits4, int k)
   else
     asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(idx4), "v"(bits4));
   return r;
+#endif
 }
 
 // Test the 8 children of wide node `child` against the ray (oct4 = the ray's octinv in each of the four bytes, a per-ray constant the

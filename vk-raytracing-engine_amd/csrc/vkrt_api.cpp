@@ -84,6 +84,7 @@ struct vkrt_scene
   std::vector<hipEvent_t> wfEvents;
   WfTiming wfTiming{};
   bool wfTimed = false;
+  int wfTimingRounds = 0;  // rounds per frame of the last timed call (vkrt_last_trace_timing: which gaps are shade launches)
   // execution options (include/vkrt.h vkrt_option); index = option id
   std::vector<hipEvent_t> wfPool;  // events ordering the lanes of one call (kernels.h WfAsync::pool)
   int opt[VKRT_OPT_LAST + 1] = {0, 1, 1, 3, 64, VKRT_WF_SHARE_DEFAULT, VKRT_TRI_THRESHOLD_DEFAULT, 0, VKRT_WF_SHARE_FLAGS_DEFAULT, 1, 0, 0, 0,
@@ -253,6 +254,10 @@ int setDevice(const vkrt_scene* s)
 int ensureWorkingSet(vkrt_scene* s, uint32_t paths, int groups, hipStream_t stream)
 {
   groups = std::max(1, std::min(VKRT_WF_MAX_LANES, groups));
+  // wf_streams.h rec(): a record's byte offset inside a plane is a 32-bit lane offset (16 B x slot); 2^28 path records and more
+  // (16384 x 16384 pixels in one shard, ~146 GB of streams) would wrap it silently
+  if(paths >= (1u << 28))
+    return fail(VKRT_ERR_UNSUPPORTED, "wavefront mode: %u path records in one shard (limit 2^28 - 1: split the launch into shards)", paths);
   if(!s->wfMem || s->wf.capacity < paths || (int)s->wf.groups < groups)
   {
     HIP_TRY(hipStreamSynchronize(stream));  // an earlier frame may still be using the smaller buffer
@@ -582,8 +587,18 @@ int vkrt_scene_get_option(const vkrt_scene* s, int option, int* value)
 
 int vkrt_reserve(vkrt_scene* s, const vkrt_shard* shard, void* hip_stream)
 {
+  if(!s)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  // frame groups: what a vkrt_pathtrace_frames call would keep in flight under the current options
+  return vkrt_reserve_frames(s, shard, (uint32_t)std::max(1, s->opt[VKRT_OPT_WF_FRAMES_IN_FLIGHT]), hip_stream);
+}
+
+int vkrt_reserve_frames(vkrt_scene* s, const vkrt_shard* shard, uint32_t frames_per_call, void* hip_stream)
+{
   if(!s || !shard)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if(frames_per_call == 0)
+    return fail(VKRT_ERR_INVALID_ARGUMENT, "frames_per_call is 0");
   if(shard->full_width == 0 || shard->full_height == 0)
     return fail(VKRT_ERR_INVALID_ARGUMENT, "empty launch size");
   if(shard->shard_count > 1 && (shard->strip_rows == 0 || shard->shard_index >= shard->shard_count))
@@ -599,10 +614,10 @@ int vkrt_reserve(vkrt_scene* s, const vkrt_shard* shard, void* hip_stream)
   const bool wavefront = s->built ? s->wavefront : useWavefront(s);
   if(tiles == 0 || !wavefront)
     return VKRT_OK;  // the megakernel keeps its state in registers / LDS
-  // frame groups: what a vkrt_pathtrace_frames call would keep in flight under the current options
-  int rc2 = ensureWorkingSet(s, (uint32_t)tiles * 64u, s->opt[VKRT_OPT_WF_FRAMES_IN_FLIGHT], (hipStream_t)hip_stream);
+  // frame groups: what a call of frames_per_call frames keeps in flight (the balanced share of the option, wavefront.hip)
+  int rc2 = ensureWorkingSet(s, (uint32_t)tiles * 64u, framesInFlight(s, (int)std::min<uint32_t>(frames_per_call, VKRT_FRAMES_PER_BATCH)), (hipStream_t)hip_stream);
   if(rc2 == VKRT_OK)
-    rc2 = ensureEventPool(s, VKRT_FRAMES_PER_BATCH);
+    rc2 = ensureEventPool(s, (int)std::min<uint32_t>(frames_per_call, VKRT_FRAMES_PER_BATCH));
   return rc2;
 }
 
@@ -1026,11 +1041,14 @@ int vkrt_pathtrace_frames(vkrt_scene* s, const PushConstantRay* pc, const Global
       timing = &s->wfTiming;
     }
     s->wfTimed = timing != nullptr;
+    s->wfTimingRounds = (pc->samples > 0 && pc->depth > 0) ? pc->samples * (pc->depth + 1) : 0;
     HIP_TRY(hipEventRecord(s->evStart, stream));
     WfOptions wo;
     wo.subframes = s->opt[VKRT_OPT_WF_SUBFRAMES];
     wo.travBlock = (s->dev.watertight || s->dev.dissolve) ? 64 : s->opt[VKRT_OPT_WF_TRAV_BLOCK];  // (the non-default triangle modes exist for the default workgroup only)
     wo.inFlight = framesInFlight(s, (int)n_frames);
+    if(timing)
+      timing->used = 0;  // one timing record per call: the batches of a long call append to it
     for(uint32_t first = 0; first < n_frames; first += VKRT_FRAMES_PER_BATCH)
     {
       TraceParams Pb = P;
@@ -1253,12 +1271,12 @@ int vkrt_counters_read(vkrt_scene* s, vkrt_counters* out)
   HIP_TRY(hipDeviceSynchronize());
   DevCounters h;
   HIP_TRY(hipMemcpy(&h, s->counters, sizeof h, hipMemcpyDeviceToHost));
-  unsigned long long t[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for(int sl = 0; sl < VKRT_COUNTER_SLOTS; sl++)
-    for(int k = 0; k < 11; k++) t[k] += h.v[sl][k];
+    for(int k = 0; k < 12; k++) t[k] += h.v[sl][k];
   out->rays_closest = t[0]; out->rays_shadow = t[1]; out->hits = t[2]; out->diffuse_hits = t[3];
   out->tex_taps = t[4]; out->pixels = t[5]; out->nodes_visited = t[6]; out->tris_tested = t[7];
-  out->wave_node_steps = t[8]; out->wave_tri_steps = t[9]; out->traversal_faults = t[10];
+  out->wave_node_steps = t[8]; out->wave_tri_steps = t[9]; out->traversal_faults = t[10]; out->pair_records = t[11];
   return VKRT_OK;
 }
 
@@ -1292,6 +1310,17 @@ int vkrt_last_trace_timing(vkrt_scene* s, vkrt_trace_timing* out)
       out->traverse_ms += ms;
     }
     out->traverse_launches = (uint32_t)s->wfTiming.used;
+    // the shade launch of round r sits between the traversal launches of rounds r and r + 1 on the same stream
+    const int rounds = s->wfTimingRounds;
+    for(int k = 0; k + 1 < s->wfTiming.used; k++)
+    {
+      if(rounds > 0 && (k + 1) % rounds == 0)
+        continue;  // a frame ends here: its last shade launch is followed by the next frame's begin
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, s->wfEvents[2 * k + 1], s->wfEvents[2 * k + 2]));
+      out->shade_ms += ms;
+      out->shade_launches++;
+    }
   }
   else if(!s->wavefront)
   {

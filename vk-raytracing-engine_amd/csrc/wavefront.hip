@@ -544,8 +544,6 @@ hipError_t vkrt_launch_wavefront(const TraceParams& P, const WfBuffers& B, const
   hipError_t e;
   if(L <= 1)
   {
-    if(timing)
-      timing->used = 0;
     for(int k = 0; k < frames; k++)
     {
       TraceParams Q = frameParams(P, k, seedStep);

@@ -61,6 +61,7 @@ void k_wf_traverse(const TraceParams P, const WfBuffers B, const int round)
     // every slot below the counts is traced exactly once: the ray counters of the launch are the stream counts
     if(cC + cP) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][0], (unsigned long long)cC + cP);
     if(cS + cP) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][1], (unsigned long long)cS + cP);
+    if(cP) atomicAdd(&P.counters->v[round % VKRT_COUNTER_SLOTS][11], (unsigned long long)cP);  // pair records (vkrt_counters.pair_records)
   }
   // block ranges: [closest rays of C][closest rays of P][shadow rays of S][shadow rays of P]
   const unsigned nC = (cC + TB - 1) / TB, nP = (cP + TB - 1) / TB, nS = (cS + TB - 1) / TB;

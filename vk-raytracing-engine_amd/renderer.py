@@ -70,9 +70,14 @@ class Renderer:
         _check(self.lib.vkrt_scene_get_option(self._h, int(option), C.byref(v)), "vkrt_scene_get_option")
         return int(v.value)
 
-    def reserve(self, shard, stream=None):
-        """Size the working set for launches of this shard geometry (no allocation / host sync inside later pathtrace calls)."""
-        _check(self.lib.vkrt_reserve(self._h, C.byref(shard), C.c_void_p(stream.cuda_stream) if stream is not None else None), "vkrt_reserve")
+    def reserve(self, shard, stream=None, frames_per_call=None):
+        """Size the working set for launches of this shard geometry (no allocation / host sync inside later pathtrace calls);
+        frames_per_call: the frames the caller hands to one pathtrace_frames call (None: whatever the options keep in flight)."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        if frames_per_call is None:
+            _check(self.lib.vkrt_reserve(self._h, C.byref(shard), st), "vkrt_reserve")
+        else:
+            _check(self.lib.vkrt_reserve_frames(self._h, C.byref(shard), int(frames_per_call), st), "vkrt_reserve_frames")
 
     def build(self, kind="ploc"):
         flags = {"sah": abi.VKRT_BUILD_SAH_HOST, "lbvh": abi.VKRT_BUILD_LBVH_GPU, "ploc": abi.VKRT_BUILD_PLOC_GPU}[kind]
@@ -216,7 +221,7 @@ class Renderer:
         t = abi.TraceTiming()
         _check(self.lib.vkrt_last_trace_timing(self._h, C.byref(t)), "vkrt_last_trace_timing")
         return {"total_ms": float(t.total_ms), "traverse_ms": float(t.traverse_ms), "traverse_launches": int(t.traverse_launches),
-                "mode": "wavefront" if t.mode == 1 else "megakernel"}
+                "mode": "wavefront" if t.mode == 1 else "megakernel", "shade_ms": float(t.shade_ms), "shade_launches": int(t.shade_launches)}
 
     def trace_rays(self, origins, directions, tmin=0.001, tmax=10000.0, any_hit=False):
         o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
