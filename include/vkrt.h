@@ -250,7 +250,11 @@ enum vkrt_option {
                                    that are large against the scene grid enter the tree as several references, each with the box of one piece of
                                    the triangle.  Only references multiply (a copy of the 48-byte record per reference): the hit test, the triangle id
                                    of the tie rule and every pixel are unchanged.  vkrt_accel_info.reference_count reports the result.
-                                   env VKRT_SPLIT_BUDGET */
+                                   WHEN TO SET IT (measured, profiles/r05_split_rotated.jsonl): 10-30 for scenes whose large triangles are
+                                   not aligned with the coordinate axes -- a building rotated 45 degrees about y traces +14 % faster, one
+                                   rotated 35 / 20 degrees about y / x +97 % (the box of a room-sized diagonal triangle is mostly empty:
+                                   61 -> 30 triangles tested per ray); 0 for axis-aligned architecture and for finely tessellated meshes,
+                                   where the extra references cost 1-8 %.  env VKRT_SPLIT_BUDGET */
   VKRT_OPT_LAST            = 14,
   VKRT_INFO_ANYHIT_ORDER   = 100 /* read-only (vkrt_scene_get_option; set is refused): the child-order bits (2 | 4) that the last vkrt_accel_build
                                    resolved VKRT_OPT_WF_SHARE_FLAGS to, i.e. what bit 3 ("automatic") decided for this scene; 0 before a build */

@@ -62,6 +62,23 @@ def timed_frames(r, frames, W, H, cam, spp, depth, lights, shard=None, image=Non
     return image, ms, (c["rays_closest"] + c["rays_shadow"]) / frames
 
 
+def timed_frames_call(r, frames, W, H, cam, spp, depth, lights, per_call, shard=None, image=None, seed0=0, frame0=0):
+    """The same through vkrt_pathtrace_frames, `per_call` frames per library call (frames in flight inside the call)."""
+    torch.cuda.synchronize()
+    r.reset_counters()
+    t0 = time.perf_counter()
+    f = 0
+    while f < frames:
+        n = min(per_call, frames - f)
+        pc = make_push_constants(samples=spp, depth=depth, frame=frame0 + f, lights_count=lights)
+        image = r.pathtrace_frames(pc, cam, W, H, n, seed=seed0 + f, shard=shard, image=image)
+        f += n
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / frames
+    c = r.counters()
+    return image, ms, (c["rays_closest"] + c["rays_shadow"]) / frames
+
+
 def tessellation_block(a, out, lights, threads):
     # ---- C3 on Sponza-like tessellation: the same atrium with room-sized wall triangles, needle mouldings, strip drapery and dense
     #      small detail (atrium variant "nonuniform"), beside the uniform one, for the three builders -- is the headline number a
@@ -102,6 +119,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "configs.json"))
     ap.add_argument("--cpu-rows", type=int, default=24, help="rows of each image the oracle renders for the parity figure")
     ap.add_argument("--only-tessellation", action="store_true", help="only the uniform vs Sponza-like tessellation block")
+    ap.add_argument("--no-tessellation", action="store_true", help="skip the tessellation block")
+    ap.add_argument("--only-hybrid-frames", type=int, default=0, help="render this many hybrid frames (C5) and exit: the workload of the rocprofv3 kernel-stats pass")
     a = ap.parse_args()
     if a.only_tessellation:
         out = {"device": torch.cuda.get_device_name(0), "cpu_threads": min(16, os.cpu_count() or 1), "configs": {}}
@@ -109,6 +128,24 @@ def main():
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         json.dump(out, open(a.out, "w"), indent=1)
         print("wrote", a.out)
+        return
+    if a.only_hybrid_frames:
+        flat, info = atrium.build_atrium(262144, seed=1)
+        lights = len(flat.lights)
+        r = Renderer(flat, device=0, build="ploc")
+        W, H = 1920, 1080
+        cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
+        pc = make_push_constants(samples=1, depth=8, frame=0, lights_count=lights)
+        pc.useShadows, pc.useAO, pc.useGI = 1, 1, 1
+        acc = None
+        for f in range(a.only_hybrid_frames):
+            pc.frame = f
+            g = r.gbuffer_raycast(cam, W, H, lights_count=lights)
+            acc = r.hybrid_trace(pc, cam, W, H, g, seed=3 + f, accum=acc)
+            r.post(g["color"], acc, rt_mode=0, use_gi=1)
+        torch.cuda.synchronize()
+        r.close()
+        print("hybrid frames", a.only_hybrid_frames)
         return
     threads = min(16, os.cpu_count() or 1)
     out = {"device": torch.cuda.get_device_name(0), "cpu_threads": threads, "configs": {}}
@@ -140,6 +177,12 @@ def main():
     for f in range(64):
         orc_c.render(make_push_constants(samples=1, depth=4, frame=f, lights_count=1), cam, W, H, seed=f, rows=rows, image=ref, threads=threads)
     res["progressive_64x1spp"] = {"ms_per_frame": ms, "ms_total": ms * 64, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref)}
+    # (a') the same 64 frames handed to the library in ONE vkrt_pathtrace_frames call (and 8 calls of 8): frames in flight
+    for per_call in (64, 8):
+        timed_frames_call(r, 8, W, H, cam, 1, 4, 1, per_call)
+        img2, ms2, rpf2 = timed_frames_call(r, 64, W, H, cam, 1, 4, 1, per_call)
+        res[f"progressive_64x1spp_frames_call_{per_call}"] = {"ms_per_frame": ms2, "ms_total": ms2 * 64, "Mrays_s": rpf2 / ms2 / 1e3,
+                                                              "bit_identical_to_single_calls": bool(torch.equal(img, img2)), **parity(img2.cpu().numpy()[rows], ref)}
     # (b) one launch x 64 spp
     timed_frames(r, 1, W, H, cam, 64, 4, 1)
     img, ms, rpf = timed_frames(r, 3, W, H, cam, 64, 4, 1, seed0=7)
@@ -148,6 +191,20 @@ def main():
     res["single_launch_64spp"] = {"ms_per_frame": ms, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref)}
     out["configs"]["C2_cornell_720p_64spp_d4_lbvh"] = res
     print("C2", res, flush=True)
+    # ---- the reference's own default frame: config.json 1280x720, pcRay.samples 1, pcRay.depth 3 (config.json:10-11, hello_vulkan.cpp:911-912)
+    dflt = {}
+    timed_frames(r, 4, W, H, cam, 1, 3, 1)
+    img, ms, rpf = timed_frames(r, 64, W, H, cam, 1, 3, 1)
+    ref = np.zeros((len(rows), W, 4), np.float32)
+    for f in range(64):
+        orc_c.render(make_push_constants(samples=1, depth=3, frame=f, lights_count=1), cam, W, H, seed=f, rows=rows, image=ref, threads=threads)
+    dflt["single_calls"] = {"ms_per_frame": ms, "fps": 1e3 / ms, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref)}
+    for per_call in (64, 8, 3):
+        timed_frames_call(r, 8, W, H, cam, 1, 3, 1, per_call)
+        img2, ms2, rpf2 = timed_frames_call(r, 64, W, H, cam, 1, 3, 1, per_call)
+        dflt[f"frames_call_{per_call}"] = {"ms_per_frame": ms2, "fps": 1e3 / ms2, "Mrays_s": rpf2 / ms2 / 1e3, "bit_identical_to_single_calls": bool(torch.equal(img, img2))}
+    out["configs"]["reference_default_frame_cornell_720p_1spp_d3"] = dflt
+    print("default frame", dflt, flush=True)
     r.close()
 
     # ---- C3 / C4 / C5: atrium
@@ -164,24 +221,31 @@ def main():
     ref = np.zeros((len(rows), W, 4), np.float32)
     for f in range(2):
         orc_a.render(make_push_constants(samples=16, depth=8, frame=f, lights_count=lights), cam, W, H, seed=f, rows=rows, image=ref, threads=threads)
+    timed_frames_call(r, 3, W, H, cam, 16, 8, lights, 6)
+    img6, ms6, rpf6 = timed_frames_call(r, 12, W, H, cam, 16, 8, lights, 6, frame0=0)
     out["configs"]["C3_atrium_1080p_16spp_d8"] = {"triangles": int(info["triangles"]) if isinstance(info, dict) and "triangles" in info else None,
-                                                  "ms_per_frame": ms, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref)}
+                                                  "ms_per_frame": ms, "Mrays_s": rpf / ms / 1e3, **parity(img.cpu().numpy()[rows], ref),
+                                                  "frames_call_6": {"ms_per_frame": ms6, "Mrays_s": rpf6 / ms6 / 1e3, "note": "bench.py's way: 6 frames per vkrt_pathtrace_frames call, 3 in flight"}}
     print("C3", out["configs"]["C3_atrium_1080p_16spp_d8"], flush=True)
 
     W, H = 3840, 2160
     cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
-    shard = make_shard(W, H, 8, 0)
-    timed_frames(r, 1, W, H, cam, 16, 8, lights, shard=shard)
-    _, ms, rpf = timed_frames(r, 3, W, H, cam, 16, 8, lights, shard=shard)
-    img, _, _ = timed_frames(r, 1, W, H, cam, 16, 8, lights, shard=shard)
-    grow = shard_row_indices(H, 8, 0)
-    pick = np.unique(np.linspace(0, len(grow) - 1, a.cpu_rows).astype(np.int64))
-    ref, _ = orc_a.render(make_push_constants(samples=16, depth=8, frame=0, lights_count=lights), cam, W, H, seed=0,
-                          rows=grow[pick].astype(np.uint32), threads=threads)
-    out["configs"]["C4_atrium_4k_16spp_d8_shard0of8"] = {"local_rows": int(len(grow)), "ms_per_frame": ms, "Mrays_s_this_gpu": rpf / ms / 1e3,
-                                                         "note": "one of eight shards; the N-GPU run is bench.py --gpus N (driver)",
-                                                         **parity(img.cpu().numpy()[pick], ref)}
-    print("C4", out["configs"]["C4_atrium_4k_16spp_d8_shard0of8"], flush=True)
+    for rank in (0, 5):
+        shard = make_shard(W, H, 8, rank)
+        timed_frames(r, 1, W, H, cam, 16, 8, lights, shard=shard)
+        _, ms, rpf = timed_frames(r, 3, W, H, cam, 16, 8, lights, shard=shard)
+        timed_frames_call(r, 3, W, H, cam, 16, 8, lights, 6, shard=shard)
+        _, ms6, rpf6 = timed_frames_call(r, 6, W, H, cam, 16, 8, lights, 6, shard=shard)
+        img, _, _ = timed_frames(r, 1, W, H, cam, 16, 8, lights, shard=shard)
+        grow = shard_row_indices(H, 8, rank)
+        pick = np.unique(np.linspace(0, len(grow) - 1, max(6, a.cpu_rows // 2)).astype(np.int64))
+        ref, _ = orc_a.render(make_push_constants(samples=16, depth=8, frame=0, lights_count=lights), cam, W, H, seed=0,
+                              rows=grow[pick].astype(np.uint32), threads=threads)
+        out["configs"][f"C4_atrium_4k_16spp_d8_shard{rank}of8"] = {"local_rows": int(len(grow)), "ms_per_frame": ms, "Mrays_s_this_gpu": rpf / ms / 1e3,
+                                                                  "frames_call_6": {"ms_per_frame": ms6, "Mrays_s_this_gpu": rpf6 / ms6 / 1e3},
+                                                                  "note": "one of eight shards; the N-GPU run is bench.py --gpus N (driver)",
+                                                                  **parity(img.cpu().numpy()[pick], ref)}
+        print("C4", rank, out["configs"][f"C4_atrium_4k_16spp_d8_shard{rank}of8"], flush=True)
 
     W, H = 1920, 1080
     cam = cam_for(W, H, **atrium.DEFAULT_CAMERA)
@@ -212,7 +276,8 @@ def main():
     print("C5", out["configs"]["C5_hybrid_atrium_1080p_shadow_ao_gi"], flush=True)
     r.close()
 
-    tessellation_block(a, out, lights, threads)
+    if not a.no_tessellation:
+        tessellation_block(a, out, lights, threads)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print("wrote", a.out)

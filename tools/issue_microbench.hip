@@ -86,7 +86,11 @@
   _(71, "v_sub_u32",            1, "v_sub_u32 %1, %1, %3") \
   _(72, "v_dot4_u32_u8",        1, "v_dot4_u32_u8 %1, %1, %3, %4") \
   _(73, "v_cvt_f16_f32",        1, "v_cvt_f16_f32 %1, %0") \
-  _(74, "v_pk_fma_f16_opsel",   1, "v_pk_fma_f16 %1, %1, %3, %4 op_sel:[0,1,0] op_sel_hi:[1,0,1]")
+  _(74, "v_pk_fma_f16_opsel",   1, "v_pk_fma_f16 %1, %1, %3, %4 op_sel:[0,1,0] op_sel_hi:[1,0,1]") \
+  _(75, "v_pk_fma_f16_subnormal_x_normal", 1, "v_pk_fma_f16 %0, %1, %3, %4") \
+  _(76, "v_fma_mixlo_f16",      1, "v_fma_mixlo_f16 %1, %0, %3, 0") \
+  _(77, "v_pk_maximum3_f16_subnormal", 1, "v_pk_maximum3_f16 %0, %1, %3, %4") \
+  _(78, "v_pk_add_f16_subnormal", 1, "v_pk_add_f16 %0, %1, %3")
 // clang-format on
 template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, unsigned long long* cyc, float s)
 {
@@ -95,7 +99,7 @@ template <int OP> __global__ __launch_bounds__(256) void k_issue(float* out, uns
   for(int i = 0; i < 8; i++) { v[i] = s + threadIdx.x + i; u[i] = threadIdx.x * 2654435761u + i; }
   for(int i = 0; i < 4; i++) { p[i] = s + i; q[i] = s * 0.25 + i; }
   const float a = s * 0.5f, b = s + 0.25f;
-  if(OP == 67) for(int i = 0; i < 8; i++) u[i] &= 0x00ff00ffu;  // binary16 subnormals in both halves: x * x + x stays subnormal
+  if(OP == 67 || OP == 75 || OP == 77 || OP == 78) for(int i = 0; i < 8; i++) u[i] &= 0x00ff00ffu;  // binary16 subnormals in both halves: x * x + x stays subnormal
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
   for(int it = 0; it < ITERS; it++)
   {
@@ -161,7 +165,7 @@ template <int OP> static void run(const char* name, int perBody, bool last)
 int main()
 {
   printf("{\n \"note\": \"per opcode: waves/SIMD -> chip-wide G wave64-instructions/s (in-kernel stamps; hipEvent), shader clock, cycles per instruction per SIMD\",\n");
-#define RUN(id, name, n, text) run<id>(name, n, id == 74);
+#define RUN(id, name, n, text) run<id>(name, n, id == 78);
   OPS(RUN)
   printf("}\n");
   return 0;
