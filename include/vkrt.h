@@ -254,10 +254,15 @@ enum vkrt_option {
                                    not aligned with the coordinate axes -- a building rotated 45 degrees about y traces +14 % faster, one
                                    rotated 35 / 20 degrees about y / x +97 % (the box of a room-sized diagonal triangle is mostly empty:
                                    61 -> 30 triangles tested per ray); 0 for axis-aligned architecture and for finely tessellated meshes,
-                                   where the extra references cost 1-8 %.  env VKRT_SPLIT_BUDGET */
+                                   where the extra references cost 1-8 %.  -1 (ABI 4) = automatic: the device builders build with a 30 %
+                                   budget and without, and keep the split tree only when its SAH cost is below 0.9 of the unsplit one
+                                   (rotated buildings: 0.70-0.82; axis-aligned and finely tessellated scenes: 0.95-1.08) -- two or three
+                                   builds of ~13 ms instead of one; VKRT_INFO_SPLIT_BUDGET reports the outcome.  env VKRT_SPLIT_BUDGET */
   VKRT_OPT_LAST            = 14,
-  VKRT_INFO_ANYHIT_ORDER   = 100 /* read-only (vkrt_scene_get_option; set is refused): the child-order bits (2 | 4) that the last vkrt_accel_build
+  VKRT_INFO_ANYHIT_ORDER   = 100, /* read-only (vkrt_scene_get_option; set is refused): the child-order bits (2 | 4) that the last vkrt_accel_build
                                    resolved VKRT_OPT_WF_SHARE_FLAGS to, i.e. what bit 3 ("automatic") decided for this scene; 0 before a build */
+  VKRT_INFO_SPLIT_BUDGET   = 101  /* read-only (ABI 4): the pre-splitting budget the last vkrt_accel_build used -- what VKRT_OPT_SPLIT_BUDGET = -1
+                                   ("automatic") resolved to: 30 or 0 */
 };
 int vkrt_scene_set_option(vkrt_scene* scene, int option, int value);
 int vkrt_scene_get_option(const vkrt_scene* scene, int option, int* value);

@@ -138,3 +138,50 @@ def test_split_with_dissolve_and_watertight_and_hybrid(sponza_like):
         assert r.counters()["traversal_faults"] == 0
         r.close()
     assert out[0] == out[40]
+
+
+def test_automatic_budget_splits_a_rotated_building_and_leaves_an_aligned_one_alone():
+    """VKRT_OPT_SPLIT_BUDGET = -1 (round 5): the device builders build with a 30 % budget and without and keep the split tree only when
+    its SAH cost is below 0.9 of the unsplit one.  On the Sponza-like tessellation turned 35 / 20 degrees about y / x (room-sized
+    diagonal triangles: profiles/r05_split_rotated.jsonl, +97 % ray rate at 30 %) that resolves to 30; on the same building aligned with
+    the axes to 0.  Pixels are the unsplit tree's either way."""
+    import atrium
+    from vkrt_amd import abi
+    from vkrt_amd.flat_scene import make_push_constants
+    from vkrt_amd.renderer import Renderer
+
+    W, H = 320, 200
+    for rot, want in ((None, 0), ((35.0, 20.0), 30)):
+        flat, info = atrium.build_atrium(60000, seed=3, variant="nonuniform")
+        camkw = dict(atrium.DEFAULT_CAMERA)
+        if rot:
+            camkw = atrium.rotate_scene(flat, camkw, *rot)
+        cam = default_camera(W, H, **camkw)
+        lights = len(flat.lights)
+        hashes, refs = {}, {}
+        for budget in (0, -1):
+            for kind in ("ploc", "lbvh"):
+                r = Renderer(flat, device=0, build=None, options={abi.VKRT_OPT_SPLIT_BUDGET: budget})
+                r.build(kind)
+                assert r.get_option(abi.VKRT_OPT_SPLIT_BUDGET) == budget  # the option keeps what the caller set
+                got = r.get_option(abi.VKRT_INFO_SPLIT_BUDGET)
+                a = r.accel_info()
+                if budget == -1:
+                    assert got == want, (rot, kind, got, a)
+                    assert (a["reference_count"] > a["triangle_count"]) == (want > 0)
+                else:
+                    assert got == 0 and a["reference_count"] == a["triangle_count"]
+                img = r.pathtrace(make_push_constants(samples=2, depth=5, frame=0, lights_count=lights), cam, W, H, seed=11)
+                c = r.counters()
+                assert c["traversal_faults"] == 0
+                hashes[(budget, kind)] = (hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), c["rays_closest"], c["rays_shadow"])
+                refs[(budget, kind)] = a["sah_cost"]
+                r.close()
+        assert len(set(hashes.values())) == 1, hashes
+        if want:
+            assert refs[(-1, "ploc")] < 0.9 * refs[(0, "ploc")]
+    # the host builder does not split: automatic means 0 there
+    r = Renderer(flat, device=0, build=None, options={abi.VKRT_OPT_SPLIT_BUDGET: -1})
+    r.build("sah")
+    assert r.get_option(abi.VKRT_INFO_SPLIT_BUDGET) == 0
+    r.close()

@@ -459,3 +459,20 @@ if __name__ == "__main__":
     target = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
     sc, info = build_atrium(target)
     print(info)
+
+
+def rotate_scene(flat, camera, ry_deg, rx_deg=0.0):
+    """The whole scene turned about y and then tilted about x (degrees), in place, with its camera: no large triangle stays aligned with
+    the coordinate axes -- the case in which triangle pre-splitting pays (profiles/r05_split_rotated.jsonl).  Lights (the reference's
+    fallback lights, hello_vulkan.cpp:247-321) stay where they are.  Returns the rotated camera keywords."""
+    ry, rx = np.deg2rad(ry_deg), np.deg2rad(rx_deg)
+    Ry = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+    R4 = np.eye(4)
+    R4[:3, :3] = Rx @ Ry
+    wm = flat.nodes["worldMatrix"].reshape(-1, 4, 4).astype(np.float64)  # column-major storage: the stored 4x4 is M^T
+    flat.nodes["worldMatrix"] = np.einsum("nij,jk->nik", wm, R4.T).reshape(flat.nodes["worldMatrix"].shape).astype(np.float32)
+    cam = dict(camera)
+    for key in ("eye", "center", "up"):
+        cam[key] = tuple((R4[:3, :3] @ np.asarray(cam[key], np.float64)).tolist())
+    return cam

@@ -22,6 +22,10 @@ if glob.glob(os.path.join(src, "stats_pipelined", "*", "*kernel_stats.csv")):
     shutil.copy(newest(os.path.join(src, "stats_pipelined", "*", "*kernel_stats.csv")), os.path.join(prof, f"{tag}_kernel_stats_pipelined.csv"))
 
 
+if glob.glob(os.path.join(src, "stats_hybrid", "*", "*kernel_stats.csv")):  # the hybrid frame (k_gbuffer / k_hybrid / k_hy_gi_init / k_wf_shade_hybrid / k_post)
+    shutil.copy(newest(os.path.join(src, "stats_hybrid", "*", "*kernel_stats.csv")), os.path.join(prof, f"{tag}_hybrid_kernel_stats.csv"))
+
+
 def bench_line(logname):
     """The JSON line bench.py printed in a profiling pass: names the sources and the workload the counters belong to."""
     try:

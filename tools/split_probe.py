@@ -21,15 +21,8 @@ for variant in os.environ.get("PROBE_VARIANTS", "default;nonuniform").split(";")
     if os.environ.get("PROBE_ROTATE"):
         # the whole building turned about y and tilted about x (degrees "ry,rx"): no large triangle is aligned with the axes any more, which
         # is where reference splitting is known to pay (the boxes of room-sized diagonal triangles are mostly empty).  Lights stay put.
-        import numpy as np
-        ry, rx = (float(v) * np.pi / 180.0 for v in (os.environ["PROBE_ROTATE"].split(",") + ["0"])[:2])
-        Ry = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
-        Rx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
-        R4 = np.eye(4); R4[:3, :3] = Rx @ Ry
-        wm = flat.nodes["worldMatrix"].reshape(-1, 4, 4).astype(np.float64)  # column-major: stored matrix = M^T
-        flat.nodes["worldMatrix"] = np.einsum("nij,jk->nik", wm, R4.T).reshape(flat.nodes["worldMatrix"].shape).astype(np.float32)
-        for key in ("eye", "center", "up"):
-            camkw[key] = tuple((R4[:3, :3] @ np.asarray(camkw[key], np.float64)).tolist())
+        ry, rx = (float(v) for v in (os.environ["PROBE_ROTATE"].split(",") + ["0"])[:2])
+        camkw = atrium.rotate_scene(flat, camkw, ry, rx)
     cam = host_py.global_uniforms(width=W, height=H, **camkw)
     r = Renderer(flat, device=0, build=None)
     for budget in [int(b) for b in os.environ.get("PROBE_BUDGETS", "0,10,20,30,50").split(",")]:

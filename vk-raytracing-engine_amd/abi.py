@@ -192,6 +192,7 @@ VKRT_OPT_GBUFFER_MIPS = 9
 VKRT_OPT_WATERTIGHT, VKRT_OPT_SKIP_DEAD_SHADOW_RAYS, VKRT_OPT_ANYHIT_DISSOLVE = 10, 11, 12
 VKRT_OPT_WF_FRAMES_IN_FLIGHT, VKRT_OPT_SPLIT_BUDGET = 13, 14
 VKRT_INFO_ANYHIT_ORDER = 100  # read-only: what the build resolved the any-hit child order to
+VKRT_INFO_SPLIT_BUDGET = 101  # read-only: the pre-splitting budget the build used (what -1 resolved to)
 
 # every symbol include/vkrt.h declares (tests check the built library exports them all)
 VKRT_SYMBOLS = [
