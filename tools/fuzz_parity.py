@@ -184,6 +184,8 @@ def run_case(seed, verbose=False, hook=None, force_opts=None):
                 m["pbrBaseColorFactor"][3] = float(rng3.choice([0.0, 0.05, 0.5, 0.95, float(rng3.random())]))
     if abi.VKRT_OPT_WF_SHARE_FLAGS in opts and rng4.random() < 0.5: opts[abi.VKRT_OPT_WF_SHARE_FLAGS] |= 16  # triangle-group donation with the drawn rules (the default has it on)
     if rng4.random() < 0.35: opts[abi.VKRT_OPT_SPLIT_BUDGET] = int(rng4.choice([10, 30, 100]))  # several references per large triangle (device builders)
+    rng5 = np.random.default_rng([seed, 5])  # round 5 (a stream of its own: every earlier seed keeps its case): the automatic budget
+    if rng5.random() < 0.15: opts[abi.VKRT_OPT_SPLIT_BUDGET] = -1
     frames_call = rng4.random() < 0.3  # the frames of the sequence in ONE vkrt_pathtrace_frames call, with whatever lanes the draw gives
     if frames_call:
         opts[abi.VKRT_OPT_WF_FRAMES_IN_FLIGHT] = int(rng4.integers(1, 5))
