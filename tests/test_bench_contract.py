@@ -212,3 +212,33 @@ def test_cpu_quota_reads_cgroup_files(tmp_path, monkeypatch):
     assert bench.cpu_quota() == 3
     monkeypatch.setattr(builtins, "open", fake({}))
     assert bench.cpu_quota() is None
+
+
+def test_round5_bench_line_carries_the_shade_and_frame_rooflines():
+    """profiles/r05_bench.json: roofline.shade prices k_wf_shade against the HBM peak with the fabric-side
+    bytes of the committed --pmc passes (raw and x2 on the read side) and with the record bytes its stream counters give;
+    roofline.frame_hbm is the whole frame's achieved HBM GB/s; cpu_baseline names the CPUs it really used."""
+    path = os.path.join(ROOT, "profiles", "r05_bench.json")
+    d = json.loads(open(path).read())
+    assert d["metric"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f32"
+    assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "valu-issue" and r["pmc_stale"] is False and 0.4 < r["frac"] < 0.8 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.6 < r["issue_mix"]["ceiling_frac_of_peak"] < 0.8 and r["frac"] < r["issue_mix"]["ceiling_frac_of_peak"]
+    s = r["shade"]
+    assert s["kernel"] == "k_wf_shade" and s["bound"] == "hbm" and s["peak"] == 8000.0 and s["pmc_stale"] is False
+    assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-9 and s["frac"] < s["frac_reads_x2"] < 1.0
+    assert abs(s["traffic"] - (s["read_bytes_per_launch_raw"] + s["write_bytes_per_launch"])) < 1.0
+    # what the kernel writes is its records: WRITE_SIZE of the counter pass and the record bytes from the stream counters agree
+    assert abs(s["write_bytes_per_launch"] / s["record_bytes_out_per_launch"] - 1.0) < 0.05
+    assert 80 < s["record_bytes_in_per_launch"] / s["records_per_launch"] < 112 and 0.05 < s["kernel_ms"] < 0.2
+    f = r["frame_hbm"]
+    assert f["unit"] == "GB/s" and abs(f["achieved"] - f["bytes_per_frame_raw"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * f["achieved"]
+    assert f["frac"] < f["frac_reads_x2"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == min(c["cpus_available_to_this_process"], c["cgroup_cpu_quota"] or c["cpus_available_to_this_process"])
+    assert abs(c["cpu_seconds_per_wall_second"] - c["cores"]) < 0.15 * c["cores"]  # the sample kept the CPUs it claims busy
+    assert c["value"] > 8 * c["single_thread"]["value"]
+    # the counter summaries the line quotes belong to the same sources
+    for name in ("pmc_issue.json", "pmc_traffic.json", "isa_mix.json"):
+        assert json.load(open(os.path.join(ROOT, "profiles", name)))["source_hash"] == d["config"]["source_hash"], name
