@@ -169,6 +169,9 @@ def test_automatic_budget_splits_a_rotated_building_and_leaves_an_aligned_one_al
                 if budget == -1:
                     assert got == want, (rot, kind, got, a)
                     assert (a["reference_count"] > a["triangle_count"]) == (want > 0)
+                    # any-hit child order (automatic): room-sized triangles that enter the tree whole switch far-first off; split into
+                    # references they do not (profiles/r05_experiments.md #144)
+                    assert r.get_option(abi.VKRT_INFO_ANYHIT_ORDER) == (4 if want else 0), (rot, kind)
                 else:
                     assert got == 0 and a["reference_count"] == a["triangle_count"]
                 img = r.pathtrace(make_push_constants(samples=2, depth=5, frame=0, lights_count=lights), cam, W, H, seed=11)

@@ -955,9 +955,13 @@ static int accelBuildOnce(vkrt_scene* s, uint32_t flags, void* hip_stream)
   // order of any-hit walks (bits 1, 2: every layout and mode; traverse.h anyhit_far_first).  Bit 3 = automatic: far-first for rays that
   // end outside the scene bounds unless the scene has LARGE triangles -- room-sized polygons sit in the leaves of the top nodes and
   // stop such rays within a step or two of a front-to-back walk, which the far-first order then only delays (measured on the two
-  // tessellations of the atrium, profiles/r03_experiments.md #94: +3.3 % on the uniform one, -2 % on the Sponza-like one)
+  // tessellations of the atrium, profiles/r03_experiments.md #94: +3.3 % on the uniform one, -2 % on the Sponza-like one).  Round 5: that
+  // holds while the large triangles enter the tree WHOLE; pre-split into references (VKRT_OPT_SPLIT_BUDGET) they are spread over the
+  // tree like any other geometry and far-first wins again -- the Sponza-like building rotated 20 / 45 / 35+20 degrees with the automatic
+  // budget: -2.2 % / -2.9 % / -2.0 % traversal time, the rotated uniform one -2.5 % ... -3.1 % (profiles/r05_experiments.md #144)
   s->dev.shareFlags = (uint32_t)s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 6u;
-  if((s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 8) && !s->hasLargeTriangles)
+  const bool largeWhole = s->hasLargeTriangles && s->info.reference_count == s->info.triangle_count;
+  if((s->opt[VKRT_OPT_WF_SHARE_FLAGS] & 8) && !largeWhole)
     s->dev.shareFlags |= 4u;
   if(s->dev.layout == 1)
   {
