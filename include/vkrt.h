@@ -246,7 +246,7 @@ enum vkrt_option {
                                    its frames into sub-frames (option 3): few, large launches overlap best.  env VKRT_WF_FRAMES_IN_FLIGHT */
   VKRT_OPT_SPLIT_BUDGET    = 14, /* [build] NOT a pixel-changing knob: triangle pre-splitting in the device builders (VKRT_BUILD_PLOC_GPU /
                                    VKRT_BUILD_LBVH_GPU), the part of PREFER_FAST_TRACE (hello_vulkan.cpp:1010, :1046) that matters on artist-made
-                                   geometry.  Value = budget of EXTRA triangle references in percent of the triangle count, 0..100 (0 = off): triangles
+                                   geometry.  Value = budget of EXTRA triangle references in percent of the triangle count, 0..100 (0 = off), or -1 = automatic (the default since ABI 4): triangles
                                    that are large against the scene grid enter the tree as several references, each with the box of one piece of
                                    the triangle.  Only references multiply (a copy of the 48-byte record per reference): the hit test, the triangle id
                                    of the tie rule and every pixel are unchanged.  vkrt_accel_info.reference_count reports the result.

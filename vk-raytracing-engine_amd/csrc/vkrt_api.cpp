@@ -25,7 +25,7 @@
 #define VKRT_WF_SHARE_DEFAULT 16
 #define VKRT_WF_SHARE_FLAGS_DEFAULT 25
 #define VKRT_WF_FRAMES_IN_FLIGHT_DEFAULT 3
-#define VKRT_SPLIT_BUDGET_DEFAULT 0
+#define VKRT_SPLIT_BUDGET_DEFAULT -1  // automatic (round 5): vkrt_accel_build decides per scene
 #include "lbvh.h"
 
 namespace {
