@@ -266,3 +266,19 @@ def test_long_calls_run_as_batches_and_equal_single_calls(cornell_flat, same_see
         t = r.last_trace_timing()
         assert t["traverse_launches"] > 8 * 4, t  # (the second batch alone has 8 frames x 4 launches: the record is not reset per batch)
     r.close()
+
+
+def test_a_shard_of_2_to_the_28_paths_is_refused_before_anything_is_allocated(cornell_flat):
+    """wf_streams.h addresses a record by a 32-bit byte offset inside its plane (16 B x slot): a shard of 2^28 path records and more
+    (16384 x 16384 pixels, ~146 GB of streams -- it would fit this part's HBM) must be refused, not wrapped; one row less
+    than that is only a matter of memory and is not reserved here."""
+    from vkrt_amd.renderer import Renderer
+    from vkrt_amd.sharding import make_shard
+
+    r = Renderer(cornell_flat, device=0, build="ploc")
+    with pytest.raises(RuntimeError, match="path records"):
+        r.reserve(make_shard(16384, 16384, 1, 0), frames_per_call=1)
+    with pytest.raises(RuntimeError, match="frames_per_call"):
+        r.reserve(make_shard(64, 64, 1, 0), frames_per_call=0)
+    r.reserve(make_shard(640, 360, 1, 0), frames_per_call=1)  # and an ordinary reservation still works afterwards
+    r.close()
